@@ -1,0 +1,67 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the FDM sampling path.
+// Wavefront = 64 lanes; MFMA fragments are expressed as 16-byte lane chunks so that the bf16
+// (v_mfma_f32_16x16x32_bf16) and exact-fp32 (v_mfma_f32_16x16x4_f32) paths share one kernel body.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fdm {
+
+typedef __bf16 bf16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_MISH = 2, ACT_GELU_ERF = 3, ACT_GELU_TANH = 4, ACT_LEAKY02 = 5 };
+
+// One MFMA "k-step" on a 16-byte-per-lane fragment pair.
+//  bf16 : 8 elements per lane  -> one 16x16x32 MFMA (lane group g = lane>>4 holds k = 8g..8g+7)
+//  fp32 : 4 elements per lane  -> four 16x16x4 MFMAs; MFMA j takes element j of both fragments, so
+//         lane group g contributes k = 4g + j; both operands use the same permutation, the sum is exact.
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+  static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    // (bit-cast the whole vector: __builtin_bit_cast(float, a[j]) on a vector element folds to element 0)
+    const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_MISH: {  // x * tanh(softplus(x)), softplus threshold 20 as torch
+      float sp = v > 20.f ? v : log1pf(expf(v));
+      return v * tanhf(sp);
+    }
+    case ACT_GELU_ERF: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    case ACT_GELU_TANH: {  // models/utils/base_model_util.py:81-94
+      float c = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      return v * (0.5f * (1.f + tanhf(c)));
+    }
+    case ACT_LEAKY02: return v > 0.f ? v : 0.2f * v;
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+}  // namespace fdm

@@ -1,0 +1,386 @@
+// HBM-bound kernels of the path: LayerNorm (wave per row), the fused scheduler update with CFG mix
+// and in-kernel Philox noise, VQ nearest-code search, InstanceNorm, conv0, and layout helpers.
+// All of these are bandwidth kernels: 16-byte accesses per lane, no re-reads, grid-stride where large.
+#pragma once
+#include "common.hpp"
+#include "../../include/fdm_hip.h"
+
+namespace fdm {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wavefront per row, row held in registers (d = 256 * NV), two-pass statistics.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  constexpr int d = 256 * NV;
+  const float* xr = p.x + (size_t)row * d;
+  const float* am = p.add_mat ? p.add_mat + (size_t)row * d : nullptr;
+  const float* at = nullptr;
+  if (p.add_tab) {
+    const int k = p.tab_step ? *p.tab_step : 0;
+    const int idx = p.tab_index ? p.tab_index[k] : k;
+    at = p.add_tab + (size_t)idx * d;
+  }
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    f32x4 a = *(const f32x4*)(xr + col);
+    if (am || at) {
+      f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (am) e = *(const f32x4*)(am + col);
+      if (at) e += *(const f32x4*)(at + col);
+      a += e;
+    }
+    v[i] = a;
+    s += (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  const float mean = wave_sum(s) * (1.f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    f32x4 c = v[i] - mean;
+    v[i] = c;
+    q += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+  }
+  const float var = wave_sum(q) * (1.f / d);
+  const float rstd = 1.f / sqrtf(var + p.eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    f32x4 gm = *(const f32x4*)(p.gamma + col);
+    f32x4 bt = *(const f32x4*)(p.beta + col);
+    f32x4 y = v[i] * rstd * gm + bt;
+    if (p.act != ACT_NONE) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = act_apply(y[j], p.act);
+    }
+    if (p.y_f32) *(f32x4*)(p.y_f32 + (size_t)row * d + col) = y;
+    if (p.y_t) {
+      if constexpr (sizeof(T) == 4) {
+        *(f32x4*)((float*)p.y_t + (size_t)row * d + col) = y;
+      } else {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 o = {(bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
+        *(bf16x4*)((bf16*)p.y_t + (size_t)row * d + col) = o;
+      }
+    }
+  }
+}
+
+template <typename T>
+static hipError_t ln_launch_t(const fdm_ln_args& a, hipStream_t s) {
+  dim3 grid((a.M + 3) / 4), block(256);
+  switch (a.d) {
+    case 256: hipLaunchKernelGGL((ln_kernel<T, 1>), grid, block, 0, s, a); break;
+    case 512: hipLaunchKernelGGL((ln_kernel<T, 2>), grid, block, 0, s, a); break;
+    case 1024: hipLaunchKernelGGL((ln_kernel<T, 4>), grid, block, 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller: counter = (element/4, step, global clip, 0), key = seed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3,
+                                              unsigned k0, unsigned k1, unsigned out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const unsigned n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigned quad, unsigned step, unsigned clip) {
+  unsigned r[4];
+  philox4x32_10(quad, step, clip, 0u, (unsigned)seed, (unsigned)(seed >> 32), r);
+  const float k = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)r[0] + 0.5f) * k, u1 = (float)r[1] * k;
+  const float u2 = ((float)r[2] + 0.5f) * k, u3 = (float)r[3] * k;
+  const float ra = sqrtf(-2.f * logf(fminf(u0, 1.f))), rb = sqrtf(-2.f * logf(fminf(u2, 1.f)));
+  float s0, c0, s1, c1;
+  sincosf(6.283185307179586f * u1, &s0, &c0);
+  sincosf(6.283185307179586f * u3, &s1, &c1);
+  return f32x4{ra * c0, ra * s0, rb * c1, rb * s1};
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scheduler step (DDPM posterior sample / DDIM eta=0 update / CFG mix), 16 B per lane.
+// Explicit _rn operations (no FMA contraction) so the fp32 result is bit-identical to the
+// reference's unfused torch expression order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sched_kernel(const fdm_sched_args p) {
+  const int k = p.step ? *p.step : 0;
+  const int t = p.tseq ? p.tseq[k] : k;
+  const long long nq = p.n / 4;
+  float c1 = 0.f, c2 = 0.f, sg = 0.f, sra = 0.f, srm1 = 1.f, san = 0.f, cn = 0.f;
+  if (p.mode == 0) { c1 = p.c1[t]; c2 = p.c2[t]; sg = p.sigma[t]; }
+  if (p.mode == 1) { sra = p.sra[t]; srm1 = p.srm1[t]; san = p.sqrt_an[k]; cn = p.c_n[k]; }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 x0 = *(const f32x4*)(p.x0 + 4 * i);
+    if (p.x0u) {
+      f32x4 u = *(const f32x4*)(p.x0u + 4 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x0[j] = __fadd_rn(u[j], __fmul_rn(p.cfg_scale, __fsub_rn(x0[j], u[j])));
+    }
+    f32x4 o;
+    if (p.mode == 2) {
+      o = x0;
+    } else {
+      const f32x4 x = *(const f32x4*)(p.x + 4 * i);
+      if (p.mode == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(c1, x0[j]), __fmul_rn(c2, x[j]));
+        if (t > 0) {
+          f32x4 z;
+          if (p.noise) {
+            z = *(const f32x4*)(p.noise + (size_t)k * p.n + 4 * i);
+          } else {
+            const long long e = 4 * i;
+            const int clip = (int)(e / p.n_per_clip);
+            z = philox_normal4(p.seed, (unsigned)((e - (long long)clip * p.n_per_clip) >> 2), (unsigned)k,
+                               (unsigned)(p.clip0 + clip));
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(o[j], __fmul_rn(sg, z[j]));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(sra, x[j]), x0[j]), srm1);
+          o[j] = __fadd_rn(__fmul_rn(x0[j], san), __fmul_rn(cn, eps));
+        }
+      }
+    }
+    *(f32x4*)(p.x_out + 4 * i) = o;
+  }
+}
+
+// single-thread epilogue kernel: advances the device-side step counter (separate tiny launch keeps
+// the main kernel free of any inter-workgroup ordering requirement)
+__global__ void step_advance_kernel(int* step) { *step += 1; }
+
+static hipError_t sched_launch(const fdm_sched_args& a, hipStream_t s) {
+  const long long nq = a.n / 4;
+  int blocks = (int)((nq + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sched_kernel, dim3(blocks), dim3(256), 0, s, a);
+  if (a.advance && a.step) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, a.step);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// small layout / elementwise helpers
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void cast_kernel(const float* src, T* dst, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dst[i] = from_f32<T>(src[i]);
+}
+
+__global__ void bias_act_kernel(const float* in, const float* vec, float* out, long long rows, int d, int act) {
+  const long long n = rows * d;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = act_apply(in[i] + (vec ? vec[i % d] : 0.f), act);
+}
+
+struct AddRowsArgs {
+  const float* a; int a_div, a_mod;
+  const float* b; int b_div, b_mod;
+  const float* c; int c_div, c_mod;
+  float* out; long long M; int d;
+};
+__global__ void add_rows_kernel(const AddRowsArgs p) {
+  const long long n = p.M * p.d;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long m = i / p.d;
+    const int col = (int)(i - m * p.d);
+    float v = p.a[((m / p.a_div) % p.a_mod) * p.d + col];
+    if (p.b) v += p.b[((m / p.b_div) % p.b_mod) * p.d + col];
+    if (p.c) v += p.c[((m / p.c_div) % p.c_mod) * p.d + col];
+    p.out[i] = v;
+  }
+}
+
+// out[b, k, :] = in[b, clamp(k - pad), :] (replicate) or 0 outside (zero)
+template <typename T>
+__global__ void pad_rows_kernel(const T* in, T* out, int B, int L, int d, int pad, int zero) {
+  const long long n = (long long)B * (L + 2 * pad) * d;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % d);
+    const long long r = i / d;
+    const int k = (int)(r % (L + 2 * pad));
+    const int b = (int)(r / (L + 2 * pad));
+    int src = k - pad;
+    T v;
+    if (zero && (src < 0 || src >= L)) {
+      v = from_f32<T>(0.f);
+    } else {
+      src = src < 0 ? 0 : (src >= L ? L - 1 : src);
+      v = in[((size_t)b * L + src) * d + col];
+    }
+    out[i] = v;
+  }
+}
+
+// [B, T, d] -> [groups, B, T + 2*pad, d/groups], zero padded in time
+template <typename T>
+__global__ void group_pad_kernel(const T* in, T* out, int B, int Tn, int d, int groups, int pad) {
+  const int dg = d / groups;
+  const long long n = (long long)groups * B * (Tn + 2 * pad) * dg;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int col = (int)(i % dg);
+    long long r = i / dg;
+    const int k = (int)(r % (Tn + 2 * pad));
+    r /= (Tn + 2 * pad);
+    const int b = (int)(r % B);
+    const int gi = (int)(r / B);
+    const int src = k - pad;
+    T v = from_f32<T>(0.f);
+    if (src >= 0 && src < Tn) v = in[((size_t)b * Tn + src) * d + gi * dg + col];
+    out[i] = v;
+  }
+}
+
+// small dense layer for one-hot / conditioning vectors: out[b, j] = act(bias[j] + sum_k W[j, k] x[b, k])
+__global__ void small_linear_kernel(const float* x, const float* W, const float* bias, float* out, int B, int K, int d, int act) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * d) return;
+  const int b = i / d, j = i - b * d;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) acc = fmaf(W[(size_t)j * K + k], x[(size_t)b * K + k], acc);
+  out[i] = act_apply(acc + (bias ? bias[j] : 0.f), act);
+}
+
+// HuBERT feature-extractor layer 0: Conv1d(1, 512, k=10, stride=5) + bias, channels-last output
+__global__ __launch_bounds__(256) void conv0_kernel(const float* wav, const float* w, const float* bias, float* out,
+                                                    int n, int T0) {
+  constexpr int TT = 16;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const float* wv = wav + (size_t)b * n;
+  float wa[10], wb[10];
+  const int oa = threadIdx.x, ob = threadIdx.x + 256;
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { wa[k] = w[oa * 10 + k]; wb[k] = w[ob * 10 + k]; }
+  const float ba = bias[oa], bb = bias[ob];
+  for (int tt = 0; tt < TT; ++tt) {
+    const int t = t0 + tt;
+    if (t >= T0) break;
+    float xa = 0.f, xb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const float x = wv[5 * t + k];
+      xa = fmaf(wa[k], x, xa);
+      xb = fmaf(wb[k], x, xb);
+    }
+    float* o = out + ((size_t)b * T0 + t) * 512;
+    o[oa] = xa + ba;
+    o[ob] = xb + bb;
+  }
+}
+
+// LeakyReLU(0.2) then InstanceNorm1d (biased variance, no affine) over L per (clip, channel);
+// thread per channel so that accesses are coalesced across channels.
+template <typename T>
+__global__ __launch_bounds__(256) void leaky_instnorm_kernel(const float* x, float* y_f32, T* y_t, int L, int d, float eps) {
+  const int ch = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (ch >= d) return;
+  const float* xp = x + (size_t)b * L * d + ch;
+  float s = 0.f;
+  for (int l = 0; l < L; ++l) s += act_apply(xp[(size_t)l * d], ACT_LEAKY02);
+  const float mean = s / L;
+  float q = 0.f;
+  for (int l = 0; l < L; ++l) {
+    const float c = act_apply(xp[(size_t)l * d], ACT_LEAKY02) - mean;
+    q += c * c;
+  }
+  const float rstd = 1.f / sqrtf(q / L + eps);
+  for (int l = 0; l < L; ++l) {
+    const float v = (act_apply(xp[(size_t)l * d], ACT_LEAKY02) - mean) * rstd;
+    const size_t o = ((size_t)b * L + l) * d + ch;
+    if (y_f32) y_f32[o] = v;
+    if (y_t) y_t[o] = from_f32<T>(v);
+  }
+}
+
+// AdaIN (utiles/adaIN.py:4-22): one wavefront per (n, c) row; unbiased variance + eps.
+__global__ __launch_bounds__(256) void adain_kernel(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= NC) return;
+  const float* c = content + (size_t)row * Lc;
+  const float* s = style + (size_t)row * Ls;
+  float a = 0.f;
+  for (int i = lane; i < Lc; i += 64) a += c[i];
+  const float cm = wave_sum(a) / Lc;
+  a = 0.f;
+  for (int i = lane; i < Lc; i += 64) { const float e = c[i] - cm; a += e * e; }
+  const float cs = sqrtf(wave_sum(a) / (Lc - 1) + eps);
+  a = 0.f;
+  for (int i = lane; i < Ls; i += 64) a += s[i];
+  const float sm = wave_sum(a) / Ls;
+  a = 0.f;
+  for (int i = lane; i < Ls; i += 64) { const float e = s[i] - sm; a += e * e; }
+  const float ss = sqrtf(wave_sum(a) / (Ls - 1) + eps);
+  for (int i = lane; i < Lc; i += 64) out[(size_t)row * Lc + i] = (c[i] - cm) / cs * ss + sm;
+}
+
+// ------------------------------------------------------------------------------------------------
+// VQ nearest code: one wavefront per latent vector; each lane scans codes lane, lane+64, ...
+// d_k = (sum_i z_i^2 + sum_i e_ki^2) - 2 * dot, every sum a sequential fmaf chain over i (the
+// documented order shared with oracle/fdm_oracle_c.c); first-min argmin; z_q = z + (e - z).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_quant_kernel(const float* z, const float* codebook, const int* book, int B, int R, int c,
+                                                       int K, float* zq_bcl, long long* idx) {
+  __shared__ float zs[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long row = (long long)blockIdx.x * 4 + wave;
+  if (row >= (long long)B * R) return;
+  const int b = (int)(row / R), r = (int)(row - (long long)b * R);
+  const float* zr = z + (size_t)row * c;
+  for (int i = lane; i < c; i += 64) zs[wave][i] = zr[i];
+  __builtin_amdgcn_wave_barrier();
+  const float* E = codebook + (size_t)(book ? book[b] : 0) * K * c;
+  float z2 = 0.f;
+  for (int i = 0; i < c; ++i) z2 = __fmaf_rn(zs[wave][i], zs[wave][i], z2);
+  float best = INFINITY;
+  int bk = 0x7fffffff;
+  for (int k = lane; k < K; k += 64) {
+    const float* e = E + (size_t)k * c;
+    float e2 = 0.f, dot = 0.f;
+    for (int i = 0; i < c; ++i) {
+      const float ev = e[i];
+      e2 = __fmaf_rn(ev, ev, e2);
+      dot = __fmaf_rn(zs[wave][i], ev, dot);
+    }
+    const float dk = __fsub_rn(__fadd_rn(z2, e2), __fmul_rn(2.f, dot));
+    if (dk < best) { best = dk; bk = k; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int ok = __shfl_xor(bk, o, 64);
+    if (ob < best || (ob == best && ok < bk)) { best = ob; bk = ok; }
+  }
+  if (bk >= K) bk = 0;   // all-NaN row: keep the access in bounds
+  if (lane == 0) idx[row] = bk;
+  const float* e = E + (size_t)bk * c;
+  for (int i = lane; i < c; i += 64) {
+    const float zv = zs[wave][i];
+    zq_bcl[((size_t)b * c + i) * R + r] = __fadd_rn(zv, __fsub_rn(e[i], zv));
+  }
+}
+
+}  // namespace fdm

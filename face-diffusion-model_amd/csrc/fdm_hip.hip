@@ -1,0 +1,302 @@
+// libfdm_hip.so: C ABI (include/fdm_hip.h) over the gfx950 kernels.  No torch, no exceptions across
+// the boundary, no allocation or synchronisation inside fdm_op_* (so a caller may capture them).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/fdm_hip.h"
+#include "attention.hpp"
+#include "elementwise.hpp"
+#include "gemm.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return fail(FDM_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+using Op = std::function<hipError_t(hipStream_t)>;
+
+}  // namespace
+
+struct fdm_prog {
+  std::vector<Op> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+namespace {
+
+thread_local fdm_prog* g_rec = nullptr;
+
+// Either record the launch closure into the program being built or launch it now.
+int submit(Op op, void* stream, const char* what) {
+  if (g_rec) {
+    g_rec->ops.push_back(std::move(op));
+    return FDM_OK;
+  }
+  hipError_t e = op((hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, what);
+  return FDM_OK;
+}
+
+bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int grid_for(long long n) {
+  long long b = (n + 255) / 256;
+  if (b > 2048) b = 2048;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* fdm_last_error(void) { return g_err.c_str(); }
+int fdm_version(void) { return 100; }
+
+int fdm_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+  return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
+  if (!a || !a->A || !a->W) return fail(FDM_ERR_ARG, "gemm: null operand");
+  if (a->M <= 0 || a->N <= 0 || a->K <= 0) return fail(FDM_ERR_SHAPE, "gemm: M,N,K must be positive (%d,%d,%d)", a->M, a->N, a->K);
+  if (a->dtype != FDM_F32 && a->dtype != FDM_BF16) return fail(FDM_ERR_ARG, "gemm: bad dtype %d", a->dtype);
+  const int bk = a->dtype == FDM_BF16 ? 64 : 32, epc = a->dtype == FDM_BF16 ? 8 : 4;
+  if (a->K % bk) return fail(FDM_ERR_SHAPE, "gemm: K=%d not a multiple of %d", a->K, bk);
+  if (a->lda % epc || a->ldw % epc || !aligned16(a->A) || !aligned16(a->W)) return fail(FDM_ERR_ARG, "gemm: operands need 16-byte aligned rows");
+  if (a->a_batch_stride % epc || a->w_batch_stride % epc) return fail(FDM_ERR_ARG, "gemm: batch strides need 16-byte alignment");
+  if (!a->out_f32 && !a->out_t && !a->out_vt) return fail(FDM_ERR_ARG, "gemm: no output");
+  if (a->out_vt && (a->vt_hd <= 0 || a->vt_L <= 0 || a->vt_Lpad < a->vt_L || a->vt_col0 < 0 || (a->N - a->vt_col0) % a->vt_hd || a->vt_col0 % 4))
+    return fail(FDM_ERR_SHAPE, "gemm: bad V^T tail");
+  if (a->bias && !aligned16(a->bias)) return fail(FDM_ERR_ARG, "gemm: bias must be 16-byte aligned");
+  fdm_gemm_args c = *a;
+  return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
+}
+
+int fdm_op_attention(const fdm_attn_args* a, void* stream) {
+  if (!a || !a->Q || !a->K || !a->Vt || !a->O) return fail(FDM_ERR_ARG, "attention: null operand");
+  if (a->hd != 64 && a->hd != 128) return fail(FDM_ERR_SHAPE, "attention: head_dim %d unsupported (64, 128)", a->hd);
+  if (a->B <= 0 || a->H <= 0 || a->L <= 0) return fail(FDM_ERR_SHAPE, "attention: B,H,L must be positive");
+  if (a->Lpad < a->L || a->Lpad % 32) return fail(FDM_ERR_SHAPE, "attention: Lpad=%d must be a multiple of 32 >= L", a->Lpad);
+  const int epc = a->dtype == FDM_BF16 ? 8 : 4;
+  if (a->ldq % epc || a->ldk % epc || a->ldo % 4 || !aligned16(a->Q) || !aligned16(a->K) || !aligned16(a->Vt) || !aligned16(a->O))
+    return fail(FDM_ERR_ARG, "attention: operands need 16-byte aligned rows");
+  if (a->slopes && a->period <= 0) return fail(FDM_ERR_ARG, "attention: period must be positive");
+  fdm_attn_args c = *a;
+  return submit([c](hipStream_t s) { return fdm::attn_launch(c, s); }, stream, "attention");
+}
+
+int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
+  if (!a || !a->x || !a->gamma || !a->beta) return fail(FDM_ERR_ARG, "layernorm: null operand");
+  if (a->d != 256 && a->d != 512 && a->d != 1024) return fail(FDM_ERR_SHAPE, "layernorm: d=%d unsupported (256, 512, 1024)", a->d);
+  if (a->M <= 0) return fail(FDM_ERR_SHAPE, "layernorm: M must be positive");
+  if (!a->y_f32 && !a->y_t) return fail(FDM_ERR_ARG, "layernorm: no output");
+  fdm_ln_args c = *a;
+  return submit([c](hipStream_t s) {
+    return c.dtype == FDM_BF16 ? fdm::ln_launch_t<fdm::bf16>(c, s) : fdm::ln_launch_t<float>(c, s);
+  }, stream, "layernorm");
+}
+
+int fdm_op_sched_step(const fdm_sched_args* a, void* stream) {
+  if (!a || !a->x0 || !a->x_out) return fail(FDM_ERR_ARG, "sched: null operand");
+  if (a->n <= 0 || a->n % 4) return fail(FDM_ERR_SHAPE, "sched: n=%lld must be a positive multiple of 4", a->n);
+  if (a->mode == 0 && (!a->x || !a->c1 || !a->c2 || !a->sigma)) return fail(FDM_ERR_ARG, "sched: DDPM tables missing");
+  if (a->mode == 1 && (!a->x || !a->sra || !a->srm1 || !a->sqrt_an || !a->c_n)) return fail(FDM_ERR_ARG, "sched: DDIM tables missing");
+  if (a->mode < 0 || a->mode > 2) return fail(FDM_ERR_ARG, "sched: bad mode %d", a->mode);
+  if (a->mode == 0 && !a->noise && (a->n_per_clip <= 0 || a->n_per_clip % 4)) return fail(FDM_ERR_SHAPE, "sched: n_per_clip must be a positive multiple of 4");
+  fdm_sched_args c = *a;
+  return submit([c](hipStream_t s) { return fdm::sched_launch(c, s); }, stream, "sched");
+}
+
+int fdm_op_cast(const float* src, void* dst, long long n, int dtype, void* stream) {
+  if (!src || !dst || n <= 0) return fail(FDM_ERR_ARG, "cast: bad argument");
+  return submit([=](hipStream_t s) {
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::cast_kernel<fdm::bf16>), dim3(grid_for(n)), dim3(256), 0, s, src, (fdm::bf16*)dst, n);
+    else hipLaunchKernelGGL((fdm::cast_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, src, (float*)dst, n);
+    return hipGetLastError();
+  }, stream, "cast");
+}
+
+int fdm_op_bias_act(const float* in, const float* vec, float* out, long long rows, int d, int act, void* stream) {
+  if (!in || !out || rows <= 0 || d <= 0) return fail(FDM_ERR_ARG, "bias_act: bad argument");
+  return submit([=](hipStream_t s) {
+    hipLaunchKernelGGL(fdm::bias_act_kernel, dim3(grid_for(rows * d)), dim3(256), 0, s, in, vec, out, rows, d, act);
+    return hipGetLastError();
+  }, stream, "bias_act");
+}
+
+int fdm_op_add_rows(const float* a, int a_div, int a_mod, const float* b, int b_div, int b_mod,
+                    const float* c, int c_div, int c_mod, float* out, long long M, int d, void* stream) {
+  if (!a || !out || M <= 0 || d <= 0 || a_div <= 0 || a_mod <= 0) return fail(FDM_ERR_ARG, "add_rows: bad argument");
+  if ((b && (b_div <= 0 || b_mod <= 0)) || (c && (c_div <= 0 || c_mod <= 0))) return fail(FDM_ERR_ARG, "add_rows: bad div/mod");
+  fdm::AddRowsArgs p{a, a_div, a_mod, b, b ? b_div : 1, b ? b_mod : 1, c, c ? c_div : 1, c ? c_mod : 1, out, M, d};
+  return submit([p](hipStream_t s) {
+    hipLaunchKernelGGL(fdm::add_rows_kernel, dim3(grid_for(p.M * p.d)), dim3(256), 0, s, p);
+    return hipGetLastError();
+  }, stream, "add_rows");
+}
+
+int fdm_op_small_linear(const float* x, const float* W, const float* bias, float* out, int B, int K, int d, int act, void* stream) {
+  if (!x || !W || !out || B <= 0 || K <= 0 || d <= 0) return fail(FDM_ERR_ARG, "small_linear: bad argument");
+  return submit([=](hipStream_t s) {
+    hipLaunchKernelGGL(fdm::small_linear_kernel, dim3((B * d + 255) / 256), dim3(256), 0, s, x, W, bias, out, B, K, d, act);
+    return hipGetLastError();
+  }, stream, "small_linear");
+}
+
+int fdm_op_pad_rows(const void* in, void* out, int B, int L, int d, int pad, int dtype, int zero, void* stream) {
+  if (!in || !out || B <= 0 || L <= 0 || d <= 0 || pad < 0) return fail(FDM_ERR_ARG, "pad_rows: bad argument");
+  const long long n = (long long)B * (L + 2 * pad) * d;
+  return submit([=](hipStream_t s) {
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::pad_rows_kernel<fdm::bf16>), dim3(grid_for(n)), dim3(256), 0, s, (const fdm::bf16*)in, (fdm::bf16*)out, B, L, d, pad, zero);
+    else hipLaunchKernelGGL((fdm::pad_rows_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)in, (float*)out, B, L, d, pad, zero);
+    return hipGetLastError();
+  }, stream, "pad_rows");
+}
+
+int fdm_op_group_pad(const void* in, void* out, int B, int T, int d, int groups, int pad, int dtype, void* stream) {
+  if (!in || !out || B <= 0 || T <= 0 || d <= 0 || groups <= 0 || d % groups || pad < 0) return fail(FDM_ERR_ARG, "group_pad: bad argument");
+  const long long n = (long long)B * (T + 2 * pad) * d;
+  return submit([=](hipStream_t s) {
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::group_pad_kernel<fdm::bf16>), dim3(grid_for(n)), dim3(256), 0, s, (const fdm::bf16*)in, (fdm::bf16*)out, B, T, d, groups, pad);
+    else hipLaunchKernelGGL((fdm::group_pad_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)in, (float*)out, B, T, d, groups, pad);
+    return hipGetLastError();
+  }, stream, "group_pad");
+}
+
+int fdm_op_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int n, int T0, void* stream) {
+  if (!wav || !w || !bias || !out || B <= 0 || n < 10 || T0 != (n - 10) / 5 + 1) return fail(FDM_ERR_SHAPE, "conv0: bad shape (n=%d, T0=%d)", n, T0);
+  return submit([=](hipStream_t s) {
+    hipLaunchKernelGGL(fdm::conv0_kernel, dim3((T0 + 15) / 16, B), dim3(256), 0, s, wav, w, bias, out, n, T0);
+    return hipGetLastError();
+  }, stream, "conv0");
+}
+
+int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L, int d, float eps, int dtype, void* stream) {
+  if (!x || (!y_f32 && !y_t) || B <= 0 || L <= 0 || d <= 0) return fail(FDM_ERR_ARG, "leaky_instnorm: bad argument");
+  return submit([=](hipStream_t s) {
+    dim3 grid((d + 255) / 256, B);
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::leaky_instnorm_kernel<fdm::bf16>), grid, dim3(256), 0, s, x, y_f32, (fdm::bf16*)y_t, L, d, eps);
+    else hipLaunchKernelGGL((fdm::leaky_instnorm_kernel<float>), grid, dim3(256), 0, s, x, y_f32, (float*)y_t, L, d, eps);
+    return hipGetLastError();
+  }, stream, "leaky_instnorm");
+}
+
+int fdm_op_adain(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps, void* stream) {
+  if (!content || !style || !out || NC <= 0 || Lc < 2 || Ls < 2) return fail(FDM_ERR_ARG, "adain: bad argument");
+  return submit([=](hipStream_t s) {
+    hipLaunchKernelGGL(fdm::adain_kernel, dim3((NC + 3) / 4), dim3(256), 0, s, content, style, out, NC, Lc, Ls, eps);
+    return hipGetLastError();
+  }, stream, "adain");
+}
+
+int fdm_op_vq_quant(const float* z, const float* codebook, const int* book, int B, int R, int c, int K,
+                    float* zq_bcl, long long* idx, void* stream) {
+  if (!z || !codebook || !zq_bcl || !idx) return fail(FDM_ERR_ARG, "vq_quant: null operand");
+  if (B <= 0 || R <= 0 || K <= 0 || c <= 0 || c > 128) return fail(FDM_ERR_SHAPE, "vq_quant: bad shape (c=%d must be <= 128)", c);
+  return submit([=](hipStream_t s) {
+    const long long rows = (long long)B * R;
+    hipLaunchKernelGGL(fdm::vq_quant_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, codebook, book, B, R, c, K, zq_bcl, idx);
+    return hipGetLastError();
+  }, stream, "vq_quant");
+}
+
+// ---------------------------------------------------------------------------------------------
+// step programs
+// ---------------------------------------------------------------------------------------------
+int fdm_prog_create(fdm_prog** out) {
+  if (!out) return fail(FDM_ERR_ARG, "prog_create: null out");
+  *out = new (std::nothrow) fdm_prog();
+  return *out ? FDM_OK : fail(FDM_ERR_STATE, "prog_create: out of memory");
+}
+
+int fdm_prog_destroy(fdm_prog* p) {
+  if (!p) return FDM_OK;
+  if (g_rec == p) g_rec = nullptr;
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  delete p;
+  return FDM_OK;
+}
+
+int fdm_prog_begin(fdm_prog* p) {
+  if (!p) return fail(FDM_ERR_ARG, "prog_begin: null program");
+  if (g_rec) return fail(FDM_ERR_STATE, "prog_begin: another program is recording on this thread");
+  if (p->exec) return fail(FDM_ERR_STATE, "prog_begin: program already instantiated");
+  g_rec = p;
+  return FDM_OK;
+}
+
+int fdm_prog_end(fdm_prog* p) {
+  if (!p || g_rec != p) return fail(FDM_ERR_STATE, "prog_end: program is not recording");
+  g_rec = nullptr;
+  return FDM_OK;
+}
+
+int fdm_prog_num_ops(fdm_prog* p) { return p ? (int)p->ops.size() : 0; }
+
+int fdm_prog_run(fdm_prog* p, void* stream) {
+  if (!p) return fail(FDM_ERR_ARG, "prog_run: null program");
+  if (g_rec) return fail(FDM_ERR_STATE, "prog_run: a program is still recording");
+  for (auto& op : p->ops) {
+    hipError_t e = op((hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "prog_run");
+  }
+  return FDM_OK;
+}
+
+int fdm_prog_instantiate(fdm_prog* p, void* stream) {
+  if (!p) return fail(FDM_ERR_ARG, "prog_instantiate: null program");
+  if (g_rec) return fail(FDM_ERR_STATE, "prog_instantiate: a program is still recording");
+  if (p->exec) return FDM_OK;
+  if (p->ops.empty()) return fail(FDM_ERR_STATE, "prog_instantiate: empty program");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
+  hipError_t opErr = hipSuccess;
+  for (auto& op : p->ops) {
+    opErr = op(s);
+    if (opErr != hipSuccess) break;
+  }
+  e = hipStreamEndCapture(s, &p->graph);
+  if (opErr != hipSuccess) return hip_fail(opErr, "prog_instantiate (launch during capture)");
+  if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+  e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
+  return FDM_OK;
+}
+
+int fdm_prog_replay(fdm_prog* p, int n, void* stream) {
+  if (!p || !p->exec) return fail(FDM_ERR_STATE, "prog_replay: program not instantiated");
+  for (int i = 0; i < n; ++i) {
+    hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
+  }
+  return FDM_OK;
+}
+
+}  // extern "C"

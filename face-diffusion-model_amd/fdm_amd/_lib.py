@@ -1,0 +1,100 @@
+"""ctypes binding of libfdm_hip.so (include/fdm_hip.h).  The product path has no CPU fallback:
+if the library is missing or a call fails, this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdm_hip.so")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_MISH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02 = range(6)
+
+vp, ll, ci, cf = C.c_void_p, C.c_longlong, C.c_int, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", vp), ("lda", ll), ("a_batch_stride", ll),
+                ("W", vp), ("ldw", ll), ("w_batch_stride", ll),
+                ("M", ci), ("N", ci), ("K", ci), ("batch", ci), ("dtype", ci),
+                ("bias", vp), ("bias_batch_stride", ll), ("act", ci),
+                ("resid", vp), ("ldr", ll), ("resid_row_mod", ci),
+                ("out_f32", vp), ("ldo_f32", ll), ("out_t", vp), ("ldo_t", ll),
+                ("out_batch_stride", ll),
+                ("out_vt", vp), ("vt_col0", ci), ("vt_L", ci), ("vt_Lpad", ci), ("vt_hd", ci)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("Q", vp), ("ldq", ll), ("K", vp), ("ldk", ll), ("Vt", vp), ("Lpad", ci),
+                ("O", vp), ("ldo", ll), ("B", ci), ("H", ci), ("L", ci), ("hd", ci), ("dtype", ci),
+                ("scale", cf), ("causal", ci), ("slopes", vp), ("period", ci)]
+
+
+class LnArgs(C.Structure):
+    _fields_ = [("x", vp), ("M", ci), ("d", ci), ("add_mat", vp), ("add_tab", vp),
+                ("tab_index", vp), ("tab_step", vp), ("gamma", vp), ("beta", vp), ("eps", cf),
+                ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci)]
+
+
+class SchedArgs(C.Structure):
+    _fields_ = [("x0", vp), ("x0u", vp), ("cfg_scale", cf), ("x", vp), ("x_out", vp),
+                ("n", ll), ("n_per_clip", ll), ("tseq", vp), ("step", vp), ("advance", ci),
+                ("c1", vp), ("c2", vp), ("sigma", vp), ("sra", vp), ("srm1", vp),
+                ("sqrt_an", vp), ("c_n", vp), ("noise", vp), ("seed", C.c_ulonglong), ("clip0", ci),
+                ("mode", ci)]
+
+
+# every symbol include/fdm_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "fdm_last_error": (C.c_char_p, []),
+    "fdm_version": (ci, []),
+    "fdm_device_ok": (ci, []),
+    "fdm_op_gemm": (ci, [C.POINTER(GemmArgs), vp]),
+    "fdm_op_attention": (ci, [C.POINTER(AttnArgs), vp]),
+    "fdm_op_layernorm": (ci, [C.POINTER(LnArgs), vp]),
+    "fdm_op_sched_step": (ci, [C.POINTER(SchedArgs), vp]),
+    "fdm_op_cast": (ci, [vp, vp, ll, ci, vp]),
+    "fdm_op_bias_act": (ci, [vp, vp, vp, ll, ci, ci, vp]),
+    "fdm_op_add_rows": (ci, [vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ll, ci, vp]),
+    "fdm_op_small_linear": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "fdm_op_pad_rows": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "fdm_op_group_pad": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
+    "fdm_op_conv0": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
+    "fdm_op_leaky_instnorm": (ci, [vp, vp, vp, ci, ci, ci, cf, ci, vp]),
+    "fdm_op_adain": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
+    "fdm_op_vq_quant": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "fdm_prog_create": (ci, [C.POINTER(vp)]),
+    "fdm_prog_destroy": (ci, [vp]),
+    "fdm_prog_begin": (ci, [vp]),
+    "fdm_prog_end": (ci, [vp]),
+    "fdm_prog_run": (ci, [vp, vp]),
+    "fdm_prog_instantiate": (ci, [vp, vp]),
+    "fdm_prog_replay": (ci, [vp, ci, vp]),
+    "fdm_prog_num_ops": (ci, [vp]),
+}
+
+_lib = None
+
+
+class FdmError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the bound library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FdmError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the product path)")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise FdmError(f"libfdm_hip error {code}: {lib().fdm_last_error().decode()}")

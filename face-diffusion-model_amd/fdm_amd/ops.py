@@ -1,0 +1,174 @@
+"""Thin tensor-level wrappers over the C ABI (raw pointers + the current HIP stream).
+
+torch is used only as the owner of device memory and of the stream; every arithmetic operation on
+the product path is a libfdm_hip.so kernel.  All wrappers raise if a tensor is not a contiguous
+CUDA(HIP) tensor: there is no CPU fallback."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32,
+                   AttnArgs, GemmArgs, LnArgs, SchedArgs, check, lib)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.FdmError("fdm_amd ops need device tensors (no CPU fallback on the product path)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def tdtype(code):
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def code_of(t):
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise _lib.FdmError(f"unsupported dtype {t.dtype}")
+
+
+def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=None, ldr=None, resid_row_mod=0,
+         out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
+         out_vt=None, vt_col0=0, vt_L=0, vt_Lpad=0, vt_hd=0):
+    a = GemmArgs()
+    a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
+    a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
+    a.M, a.N, a.K, a.batch, a.dtype = M, N, K, batch, code_of(A)
+    if W.dtype != A.dtype:
+        raise _lib.FdmError("gemm: A and W dtypes differ")
+    a.bias, a.bias_batch_stride, a.act = _p(bias), bias_bs, act
+    a.resid, a.ldr, a.resid_row_mod = _p(resid), (ldr if ldr is not None else N), resid_row_mod
+    a.out_f32, a.ldo_f32 = _p(out_f32), (ldo_f32 if ldo_f32 is not None else N)
+    a.out_t, a.ldo_t = _p(out_t), (ldo_t if ldo_t is not None else N)
+    a.out_batch_stride = out_bs
+    a.out_vt, a.vt_col0, a.vt_L, a.vt_Lpad, a.vt_hd = _p(out_vt), vt_col0, vt_L, vt_Lpad, vt_hd
+    check(lib().fdm_op_gemm(C.byref(a), stream()))
+
+
+def attention(Q, K, Vt, O, *, B, H, L, hd, ldq, ldk, ldo, Lpad, scale, causal=False, slopes=None, period=1):
+    a = AttnArgs()
+    a.Q, a.ldq, a.K, a.ldk, a.Vt, a.Lpad = _p(Q), ldq, _p(K), ldk, _p(Vt), Lpad
+    a.O, a.ldo, a.B, a.H, a.L, a.hd, a.dtype = _p(O), ldo, B, H, L, hd, code_of(Q)
+    a.scale, a.causal, a.slopes, a.period = scale, int(causal), _p(slopes), period
+    check(lib().fdm_op_attention(C.byref(a), stream()))
+
+
+def layernorm(x, gamma, beta, M, d, *, add_mat=None, add_tab=None, tab_index=None, tab_step=None, eps=1e-5,
+              act=ACT_NONE, y_f32=None, y_t=None, dtype=F32):
+    a = LnArgs()
+    a.x, a.M, a.d, a.add_mat, a.add_tab = _p(x), M, d, _p(add_mat), _p(add_tab)
+    a.tab_index, a.tab_step, a.gamma, a.beta, a.eps = _p(tab_index), _p(tab_step), _p(gamma), _p(beta), eps
+    a.act, a.y_f32, a.y_t, a.dtype = act, _p(y_f32), _p(y_t), dtype
+    check(lib().fdm_op_layernorm(C.byref(a), stream()))
+
+
+def sched_step(mode, x0, x, x_out, n, *, x0u=None, cfg_scale=0.0, n_per_clip=0, tseq=None, step=None, advance=0,
+               c1=None, c2=None, sigma=None, sra=None, srm1=None, sqrt_an=None, c_n=None, noise=None, seed=0, clip0=0):
+    a = SchedArgs()
+    a.x0, a.x0u, a.cfg_scale, a.x, a.x_out = _p(x0), _p(x0u), cfg_scale, _p(x), _p(x_out)
+    a.n, a.n_per_clip, a.tseq, a.step, a.advance = n, n_per_clip, _p(tseq), _p(step), advance
+    a.c1, a.c2, a.sigma, a.sra, a.srm1 = _p(c1), _p(c2), _p(sigma), _p(sra), _p(srm1)
+    a.sqrt_an, a.c_n, a.noise, a.seed, a.clip0, a.mode = _p(sqrt_an), _p(c_n), _p(noise), seed, clip0, mode
+    check(lib().fdm_op_sched_step(C.byref(a), stream()))
+
+
+def cast(src, dst):
+    check(lib().fdm_op_cast(_p(src), _p(dst), src.numel(), code_of(dst), stream()))
+
+
+def to_operand(src_f32, dtype):
+    """fp32 device tensor -> operand dtype copy (identity for fp32)."""
+    if dtype == F32:
+        return src_f32
+    dst = torch.empty(src_f32.shape, dtype=torch.bfloat16, device=src_f32.device)
+    cast(src_f32.contiguous(), dst)
+    return dst
+
+
+def bias_act(inp, vec, out, rows, d, act):
+    check(lib().fdm_op_bias_act(_p(inp), _p(vec), _p(out), rows, d, act, stream()))
+
+
+def add_rows(out, M, d, a, a_div, a_mod, b=None, b_div=1, b_mod=1, c=None, c_div=1, c_mod=1):
+    check(lib().fdm_op_add_rows(_p(a), a_div, a_mod, _p(b), b_div, b_mod, _p(c), c_div, c_mod, _p(out), M, d, stream()))
+
+
+def small_linear(x, W, bias, out, B, K, d, act=ACT_NONE):
+    check(lib().fdm_op_small_linear(_p(x), _p(W), _p(bias), _p(out), B, K, d, act, stream()))
+
+
+def pad_rows(inp, out, B, L, d, pad, zero=False):
+    check(lib().fdm_op_pad_rows(_p(inp), _p(out), B, L, d, pad, code_of(inp), int(zero), stream()))
+
+
+def group_pad(inp, out, B, T, d, groups, pad):
+    check(lib().fdm_op_group_pad(_p(inp), _p(out), B, T, d, groups, pad, code_of(inp), stream()))
+
+
+def conv0(wav, w, bias, out, B, n, T0):
+    check(lib().fdm_op_conv0(_p(wav), _p(w), _p(bias), _p(out), B, n, T0, stream()))
+
+
+def leaky_instnorm(x, B, L, d, *, y_f32=None, y_t=None, eps=1e-5, dtype=F32):
+    check(lib().fdm_op_leaky_instnorm(_p(x), _p(y_f32), _p(y_t), B, L, d, eps, dtype, stream()))
+
+
+def adain(content, style, out, NC, Lc, Ls, eps=1e-5):
+    check(lib().fdm_op_adain(_p(content), _p(style), _p(out), NC, Lc, Ls, eps, stream()))
+
+
+def vq_quant(z, codebook, book, B, R, c, K, zq_bcl, idx):
+    check(lib().fdm_op_vq_quant(_p(z), _p(codebook), _p(book), B, R, c, K, _p(zq_bcl), _p(idx), stream()))
+
+
+class Program:
+    """A recorded sequence of fdm_op_* launches, replayable as a hipGraph (fdm_prog_*)."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib().fdm_prog_create(C.byref(h)))
+        self.h = h
+        self.keep = []          # tensors referenced by raw pointer inside the program
+
+    def __enter__(self):
+        check(lib().fdm_prog_begin(self.h))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        rc = lib().fdm_prog_end(self.h)
+        if et is None:
+            check(rc)
+        return False
+
+    def hold(self, *tensors):
+        self.keep.extend(tensors)
+
+    @property
+    def num_ops(self):
+        return lib().fdm_prog_num_ops(self.h)
+
+    def run(self):
+        check(lib().fdm_prog_run(self.h, stream()))
+
+    def instantiate(self):
+        check(lib().fdm_prog_instantiate(self.h, stream()))
+
+    def replay(self, n=1):
+        check(lib().fdm_prog_replay(self.h, n, stream()))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().fdm_prog_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

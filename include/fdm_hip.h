@@ -1,0 +1,177 @@
+/* libfdm_hip.so -- C ABI of the MI355X-native FDM diffusion-sampling hot path.
+ *
+ * Drop-in boundary.  The reference is pure Python and has no FFI; the "plugin
+ * boundary" it offers is the Python class surface (FDM.forward, GaussianDiffusion.sample /
+ * ddim_sample / p_sample, HubertModel.forward, VQAutoEncoder.quant / decode).  Every entry point
+ * below names the reference interface (file:line under /root/reference) whose arithmetic it
+ * replaces.  All functions take raw device pointers, sizes and a hipStream_t (passed as void*),
+ * return 0 on success or a negative error code (message via fdm_last_error()), never throw and
+ * never synchronise the device.  Nothing here takes or returns a torch type.
+ *
+ * Two layers:
+ *   fdm_op_*    single-kernel operators (one launch on the given stream)
+ *   fdm_prog_*  a recorded sequence of operators = one "step program", captured into a hipGraph and
+ *               replayed T times with the diffusion timestep read from a device-side counter
+ *   fdm_plan_*  the denoiser + scheduler plan (weights, workspaces, tables, step program)
+ */
+#ifndef FDM_HIP_H
+#define FDM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDM_F32 0
+#define FDM_BF16 1
+
+#define FDM_ACT_NONE 0
+#define FDM_ACT_RELU 1       /* nn.TransformerDecoderLayer default activation, models/fdm_vocaset.py:45 */
+#define FDM_ACT_MISH 2       /* nn.Mish, models/fdm_vocaset.py:22,31,38 */
+#define FDM_ACT_GELU_ERF 3   /* transformers HuBERT 'gelu' */
+#define FDM_ACT_GELU_TANH 4  /* models/utils/base_model_util.py:81-94 */
+#define FDM_ACT_LEAKY02 5    /* nn.LeakyReLU(0.2), models/vq_vae_vocaset.py:206 */
+
+#define FDM_OK 0
+#define FDM_ERR_ARG (-1)
+#define FDM_ERR_SHAPE (-2)
+#define FDM_ERR_HIP (-3)
+#define FDM_ERR_STATE (-4)
+
+const char* fdm_last_error(void);
+int fdm_version(void);
+/* 1 if a gfx950 device is visible to this process, else 0 (no device is touched otherwise) */
+int fdm_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * C[M,N] = epilogue(A[M,K] * W[N,K]^T): every nn.Linear / Conv1d-as-GEMM on the path
+ * (models/fdm_vocaset.py:20-24,36-39,45-51; transformers HubertAttention/FeedForward;
+ * models/lib/base_models.py:71-87,138-174; models/vq_vae_vocaset.py:204,243).
+ * A rows may overlap (lda < K) which expresses a strided Conv1d over a channels-last signal
+ * without im2col.  v = acc + bias[n]; v = act(v); v += resid[m or m % mod][n]; stores fp32
+ * and/or operand-dtype copies; columns >= vt_col0 can be scattered transposed into a
+ * [B*H, hd, Lpad] "V^T" buffer for the attention kernel.  K must be a multiple of 32 (fp32) /
+ * 64 (bf16); A, W 16-byte aligned with lda, ldw multiples of 4 (fp32) / 8 (bf16).            */
+typedef struct fdm_gemm_args {
+  const void* A; long long lda; long long a_batch_stride;
+  const void* W; long long ldw; long long w_batch_stride;
+  int M, N, K, batch;
+  int dtype;                      /* FDM_F32 | FDM_BF16: type of A, W, out_t, out_vt */
+  const float* bias; long long bias_batch_stride;
+  int act;
+  const float* resid; long long ldr; int resid_row_mod;
+  float* out_f32; long long ldo_f32;
+  void* out_t; long long ldo_t;
+  long long out_batch_stride;     /* elements, applied to out_f32, out_t and resid (column offset) */
+  void* out_vt; int vt_col0; int vt_L; int vt_Lpad; int vt_hd;
+} fdm_gemm_args;
+int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused softmax(Q K^T * scale + bias) V for one [B, H, L, hd] problem.
+ * nn.MultiheadAttention self-attention with the causal periodic-ALiBi mask generated in-kernel
+ * (models/fdm_vocaset.py:85,95-116: mask[h,i,j] = -slope_h*floor((i-j)/period), -inf for j>i);
+ * non-causal for HuBERT (hd 64, scale 1/8) and the VQ decoder (hd 128, scale hidden^-0.5,
+ * models/lib/base_models.py:144).  Q, K: row (b*L + l), column h*hd + e, row strides ldq/ldk.
+ * Vt: [B*H, hd, Lpad] (written by fdm_op_gemm's vt tail).  O: [B*L, ldo] operand dtype.     */
+typedef struct fdm_attn_args {
+  const void* Q; long long ldq;
+  const void* K; long long ldk;
+  const void* Vt; int Lpad;
+  void* O; long long ldo;
+  int B, H, L, hd;
+  int dtype;
+  float scale;
+  int causal;
+  const float* slopes;   /* [H] device floats or NULL */
+  int period;
+} fdm_attn_args;
+int fdm_op_attention(const fdm_attn_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * y = act(LayerNorm(x + add_mat + add_tab[idx]) * gamma + beta), one wavefront per row
+ * (nn.LayerNorm eps 1e-5: decoder norm1-3 models/fdm_vocaset.py:45; HuBERT; VQ Norm
+ * models/lib/base_models.py:37-52).  add_tab row index = tab_index[*tab_step] if tab_step else
+ * tab_index[0] (device ints) -- this is how the folded cross-attention time term enters
+ * (SURVEY.md a11x).  d in {256, 512, 1024}.                                                  */
+typedef struct fdm_ln_args {
+  const float* x; int M, d;
+  const float* add_mat;               /* [M, d] or NULL */
+  const float* add_tab;               /* [rows, d] or NULL */
+  const int* tab_index; const int* tab_step;
+  const float* gamma; const float* beta; float eps;
+  int act;
+  float* y_f32; void* y_t; int dtype;
+} fdm_ln_args;
+int fdm_op_layernorm(const fdm_ln_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scheduler (GaussianDiffusion.q_posterior + p_sample, ddim_sample update, CFG mix):
+ * video_diffusion_pytorch/diffusion_BIWI_encoder_decoder.py:632-656, 693-708;
+ * utiles/classifierfree.py:20-21.  All clips of the batch share the timestep (a3).
+ * tables are fp32 [T_train] arrays; the current step k = *step (device int, incremented by the
+ * kernel when advance != 0), t = tseq[k].  x0u != NULL enables the CFG mix
+ * x0 = x0u + cfg_scale*(x0 - x0u) before the update.
+ * DDPM: x' = c1[t]*x0 + c2[t]*x + sigma[t]*z, z = 0 when t == 0.  z comes from `noise`
+ * (+ k*n elements) if non-NULL, else Philox4x32-10/Box-Muller keyed by (seed, clip0 + clip, k).
+ * DDIM (eta = 0): eps = (sra[t]*x - x0)/srm1[t]; x' = x0*sqrt_an[k] + c_n[k]*eps.           */
+typedef struct fdm_sched_args {
+  const float* x0; const float* x0u; float cfg_scale;
+  const float* x; float* x_out;
+  long long n; long long n_per_clip;
+  const int* tseq; int* step; int advance;
+  const float* c1; const float* c2; const float* sigma;      /* DDPM tables, indexed by t */
+  const float* sra; const float* srm1;                       /* DDIM tables, indexed by t */
+  const float* sqrt_an; const float* c_n;                    /* DDIM tables, indexed by step k */
+  const float* noise; unsigned long long seed; int clip0;
+  int mode;                                                  /* 0 DDPM, 1 DDIM, 2 CFG mix only (x_out = mix) */
+} fdm_sched_args;
+int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small elementwise / layout operators.                                                      */
+/* dst_t[i] = (dtype) src_f32[i] */
+int fdm_op_cast(const float* src, void* dst, long long n, int dtype, void* stream);
+/* out[r, :] = act(in[r, :] + vec[:]) -- e.g. tau table = Mish(W_t^T + b_t), models/fdm_vocaset.py:71-72 */
+int fdm_op_bias_act(const float* in, const float* vec, float* out, long long rows, int d, int act, void* stream);
+/* out[m, :] = a[(m / a_div) % a_mod, :] (+ b[(m / b_div) % b_mod, :]) (+ c[...]) -- conditioning addend
+ * table: PE[l] + style[b] (+ emotion[b]), models/fdm_vocaset.py:75-84 */
+int fdm_op_add_rows(const float* a, int a_div, int a_mod, const float* b, int b_div, int b_mod,
+                    const float* c, int c_div, int c_mod, float* out, long long M, int d, void* stream);
+/* out[b, :] = act(W[d, K] x[b, :] + bias) for conditioning one-hots (K <= 64): style_embedd /
+ * emotion_embedd, models/fdm_vocaset.py:34,75; models/fdm_vqvae_mead.py:34-36,85 */
+int fdm_op_small_linear(const float* x, const float* W, const float* bias, float* out, int B, int K, int d,
+                        int act, void* stream);
+/* out[b, k, :] = in[b, clamp(k - pad, 0, L-1), :] for k in [0, L + 2*pad): replicate padding, channels-last */
+int fdm_op_pad_rows(const void* in, void* out, int B, int L, int d, int pad, int dtype, int zero, void* stream);
+/* HuBERT conv layer 0: wav [B, n] -> out [B, T0, 512], Conv1d(1, 512, k=10, s=5) + bias */
+int fdm_op_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int n, int T0, void* stream);
+/* per-(clip, channel) InstanceNorm1d over L after LeakyReLU(0.2): models/vq_vae_vocaset.py:204-209 */
+int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L, int d, float eps, int dtype, void* stream);
+/* AdaIN (utiles/adaIN.py:4-22): content, style [N, C, Lc], [N, C, Ls] -> out [N, C, Lc] */
+int fdm_op_adain(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps, void* stream);
+/* regroup [B, T, d] -> [groups, B, T + 2*pad, d/groups] zero padded (HuBERT positional conv input) */
+int fdm_op_group_pad(const void* in, void* out, int B, int T, int d, int groups, int pad, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * VectorQuantizer.forward (models/lib/quantizer.py:35-64, models/vq_vae_emotion.py:221-252):
+ * d_k = (sum z^2 + sum e_k^2) - 2 z.e_k, first-min argmin, z_q = z + (e - z), output
+ * permuted to [B, c, R] (R = L*G rows per clip).  book[b] selects the 256-code slice.        */
+int fdm_op_vq_quant(const float* z, const float* codebook, const int* book, int B, int R, int c, int K,
+                    float* zq_bcl, long long* idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Step programs: record fdm_op_* calls, run them eagerly or as a hipGraph replayed n times.  */
+typedef struct fdm_prog fdm_prog;
+int fdm_prog_create(fdm_prog** out);
+int fdm_prog_destroy(fdm_prog* p);
+int fdm_prog_begin(fdm_prog* p);            /* subsequent fdm_op_* calls on this thread are recorded, not launched */
+int fdm_prog_end(fdm_prog* p);
+int fdm_prog_run(fdm_prog* p, void* stream);                 /* eager: launch every recorded op */
+int fdm_prog_instantiate(fdm_prog* p, void* stream);         /* capture into a hipGraph */
+int fdm_prog_replay(fdm_prog* p, int n, void* stream);       /* launch the graph n times */
+int fdm_prog_num_ops(fdm_prog* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,293 @@
+"""GPU: every fdm_op_* kernel against a plain fp32 torch (CPU) reference of the same operator,
+called through the C ABI.  fp32 kernels: 2e-5 relative-to-scale; bf16 kernels: 2e-2 (bf16 inputs have
+8 significant bits; references are computed from the bf16-rounded inputs so only accumulation differs)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from fdm_amd import ops  # noqa: E402
+from fdm_amd._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32)  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def act_ref(x, act):
+    if act == ACT_RELU:
+        return torch.relu(x)
+    if act == ACT_MISH:
+        return F.mish(x)
+    if act == ACT_GELU_ERF:
+        return F.gelu(x)
+    if act == ACT_GELU_TANH:
+        return x * 0.5 * (1.0 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))
+    if act == ACT_LEAKY02:
+        return F.leaky_relu(x, 0.2)
+    return x
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N,K,act", [(7, 256, 256, ACT_MISH), (100, 1024, 1024, ACT_NONE), (800, 3072, 1024, ACT_RELU),
+                                       (33, 15069, 1024, ACT_NONE), (257, 192, 2048, ACT_GELU_ERF),
+                                       (1600, 2048, 1024, ACT_GELU_TANH), (130, 1024, 5120, ACT_LEAKY02)])
+def test_gemm(dtype, M, N, K, act):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    td = ops.tdtype(dtype)
+    A = torch.randn(M, K, generator=g).to(td)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(td)
+    bias = torch.randn(N + 3, generator=g)[:N].contiguous()
+    resid = torch.randn(M, N, generator=g)
+    ref = act_ref(A.float() @ W.float().t() + bias, act) + resid
+    o32 = torch.zeros(M, N, device=DEV)
+    ot = torch.zeros(M, N, device=DEV, dtype=td)
+    ops.gemm(A.to(DEV), W.to(DEV), M, N, K, bias=bias.to(DEV), act=act, resid=resid.to(DEV), out_f32=o32, out_t=ot)
+    torch.cuda.synchronize()
+    tol = 2e-5 if dtype == F32 else 1e-2
+    assert rel(o32, ref) < tol
+    assert rel(ot.float(), ref) < (tol if dtype == F32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_overlapping_rows_is_strided_conv(dtype):
+    """lda < K: Conv1d(512, 512, k=3, stride=2) over a channels-last signal, no im2col."""
+    g = torch.Generator().manual_seed(5)
+    td = ops.tdtype(dtype)
+    T, Cc, k, s = 101, 512, 3, 2
+    x = torch.randn(T, Cc, generator=g).to(td)
+    w = (torch.randn(Cc, Cc, k, generator=g) / math.sqrt(Cc * k)).to(td)
+    ref = F.conv1d(x.float().t().unsqueeze(0), w.float(), stride=s)[0].t()
+    To = (T - k) // s + 1
+    wr = w.permute(0, 2, 1).contiguous().view(Cc, k * Cc)
+    out = torch.zeros(To, Cc, device=DEV)
+    ops.gemm(x.to(DEV), wr.to(DEV), To, Cc, k * Cc, lda=s * Cc, out_f32=out)
+    torch.cuda.synchronize()
+    assert rel(out, ref) < (2e-5 if dtype == F32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_batched_column_groups_and_row_broadcast_residual(dtype):
+    g = torch.Generator().manual_seed(6)
+    td = ops.tdtype(dtype)
+    G, M, K, Ng = 4, 50, 128, 64
+    A = torch.randn(G, M, K, generator=g).to(td)
+    W = (torch.randn(G, Ng, K, generator=g) / math.sqrt(K)).to(td)
+    bias = torch.randn(G * Ng, generator=g)
+    rrow = torch.randn(1, G * Ng, generator=g)
+    ref = torch.cat([A[i].float() @ W[i].float().t() for i in range(G)], 1) + bias + rrow
+    out = torch.zeros(M, G * Ng, device=DEV)
+    ops.gemm(A.to(DEV), W.to(DEV), M, Ng, K, batch=G, a_bs=M * K, w_bs=Ng * K, bias=bias.to(DEV), bias_bs=Ng,
+             resid=rrow.to(DEV), ldr=G * Ng, resid_row_mod=1, out_f32=out, ldo_f32=G * Ng, out_bs=Ng)
+    torch.cuda.synchronize()
+    assert rel(out, ref) < (2e-5 if dtype == F32 else 1e-2)
+
+
+def mha_ref(q, k, v, scale, bias):
+    s = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    if bias is not None:
+        s = s + bias
+    return torch.einsum("bhij,bhjd->bhid", torch.softmax(s, -1), v)
+
+
+def alibi(H, L, period, slopes):
+    i = torch.arange(L).view(L, 1)
+    j = torch.arange(L).view(1, L)
+    m = -slopes.view(H, 1, 1) * torch.div(i - j, period, rounding_mode="floor").float()
+    return m.masked_fill((j > i).unsqueeze(0), float("-inf"))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("B,H,L,hd,causal", [(1, 2, 7, 128, True), (2, 8, 100, 128, True), (4, 8, 200, 128, True),
+                                             (1, 4, 600, 128, True), (2, 16, 98, 64, False), (1, 8, 33, 128, False),
+                                             (1, 16, 498, 64, False)])
+def test_attention_via_qkv_gemm_layout(dtype, B, H, L, hd, causal):
+    """QKV produced by the GEMM (V scattered transposed), then the fused attention kernel."""
+    g = torch.Generator().manual_seed(L + hd)
+    td = ops.tdtype(dtype)
+    d = H * hd
+    x = torch.randn(B * L, d, generator=g).to(td)
+    Wqkv = (torch.randn(3 * d, d, generator=g) / math.sqrt(d)).to(td)
+    bqkv = 0.1 * torch.randn(3 * d, generator=g)
+    Lpad = (L + 31) // 32 * 32
+    qkv_t = torch.zeros(B * L, 3 * d, device=DEV, dtype=td)
+    vt = torch.zeros(B * H, hd, Lpad, device=DEV, dtype=td)
+    ops.gemm(x.to(DEV), Wqkv.to(DEV), B * L, 3 * d, d, bias=bqkv.to(DEV), out_t=qkv_t, ldo_t=3 * d,
+             out_vt=vt, vt_col0=2 * d, vt_L=L, vt_Lpad=Lpad, vt_hd=hd)
+    slopes = torch.tensor([2.0 ** (-(i + 1)) for i in range(H)])
+    scale = 1.0 / math.sqrt(hd) if causal else (1.0 / 32 if hd == 128 else 0.125)
+    o = torch.zeros(B * L, d, device=DEV, dtype=td)
+    ops.attention(qkv_t, qkv_t[:, d:], vt, o, B=B, H=H, L=L, hd=hd, ldq=3 * d, ldk=3 * d, ldo=d, Lpad=Lpad,
+                  scale=scale, causal=causal, slopes=slopes.to(DEV) if causal else None, period=30)
+    torch.cuda.synchronize()
+    qkv = (x.float() @ Wqkv.float().t() + bqkv)
+    if dtype == BF16:
+        qkv = qkv.to(td).float()
+    # GEMM-produced V^T matches the reference V
+    vref = qkv[:, 2 * d:].view(B, L, H, hd).permute(0, 2, 3, 1)
+    assert rel(vt.view(B, H, hd, Lpad)[..., :L].float(), vref) < (2e-5 if dtype == F32 else 1e-2)
+    q, k, v = [t.view(B, L, H, hd).transpose(1, 2) for t in qkv.split(d, 1)]
+    ref = mha_ref(q, k, v, scale, alibi(H, L, 30, slopes) if causal else None).transpose(1, 2).reshape(B * L, d)
+    assert rel(o.float(), ref) < (3e-5 if dtype == F32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,d,act", [(5, 256, ACT_NONE), (800, 1024, ACT_NONE), (333, 512, ACT_GELU_ERF)])
+def test_layernorm_with_addends(dtype, M, d, act):
+    g = torch.Generator().manual_seed(M + d)
+    x = torch.randn(M, d, generator=g) * 2 + 0.3
+    am = torch.randn(M, d, generator=g)
+    tab = torch.randn(10, d, generator=g)
+    gamma = 1 + 0.1 * torch.randn(d, generator=g)
+    beta = 0.1 * torch.randn(d, generator=g)
+    tidx = torch.tensor([3, 7, 9], dtype=torch.int32)
+    step = torch.tensor([1], dtype=torch.int32)
+    ref = act_ref(F.layer_norm(x + (am + tab[7]), (d,), gamma, beta, 1e-5), act)
+    y32 = torch.zeros(M, d, device=DEV)
+    yt = torch.zeros(M, d, device=DEV, dtype=ops.tdtype(dtype))
+    ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), M, d, add_mat=am.to(DEV), add_tab=tab.to(DEV),
+                  tab_index=tidx.to(DEV), tab_step=step.to(DEV), act=act, y_f32=y32, y_t=yt, dtype=dtype)
+    torch.cuda.synchronize()
+    assert rel(y32, ref) < 1e-5
+    assert rel(yt.float(), ref) < (1e-5 if dtype == F32 else 1e-2)
+
+
+def test_sched_ddpm_ddim_cfg_bit_exact_vs_unfused_torch():
+    g = torch.Generator().manual_seed(11)
+    n = 4 * 1000
+    x0, x0u, x, z = [torch.randn(n, generator=g) for _ in range(4)]
+    tab = [torch.rand(1000, generator=g) + 0.1 for _ in range(7)]
+    tseq = torch.tensor([999, 500, 1, 0], dtype=torch.int32)
+    for k in range(4):
+        t = int(tseq[k])
+        step = torch.tensor([k], dtype=torch.int32, device=DEV)
+        out = torch.zeros(n, device=DEV)
+        noise = torch.stack([z * (i + 1) for i in range(4)])
+        ops.sched_step(0, x0.to(DEV), x.to(DEV), out, n, tseq=tseq.to(DEV), step=step, c1=tab[0].to(DEV),
+                       c2=tab[1].to(DEV), sigma=tab[2].to(DEV), noise=noise.to(DEV))
+        ref = tab[0][t] * x0 + tab[1][t] * x
+        if t > 0:
+            ref = ref + tab[2][t] * noise[k]
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref), f"ddpm t={t}"
+        # DDIM + CFG mix
+        out2 = torch.zeros(n, device=DEV)
+        ops.sched_step(1, x0.to(DEV), x.to(DEV), out2, n, x0u=x0u.to(DEV), cfg_scale=2.5, tseq=tseq.to(DEV), step=step,
+                       sra=tab[3].to(DEV), srm1=tab[4].to(DEV), sqrt_an=tab[5].to(DEV), c_n=tab[6].to(DEV))
+        mix = x0u + 2.5 * (x0 - x0u)
+        eps = (tab[3][t] * x - mix) / tab[4][t]
+        ref2 = mix * tab[5][k] + tab[6][k] * eps
+        torch.cuda.synchronize()
+        assert torch.equal(out2.cpu(), ref2), f"ddim t={t}"
+    # advance increments the device counter
+    step = torch.tensor([0], dtype=torch.int32, device=DEV)
+    out = torch.zeros(n, device=DEV)
+    ops.sched_step(2, x0.to(DEV), None, out, n, x0u=x0u.to(DEV), cfg_scale=2.5, step=step, advance=1)
+    torch.cuda.synchronize()
+    assert int(step[0]) == 1 and torch.equal(out.cpu(), x0u + 2.5 * (x0 - x0u))
+
+
+def test_sched_philox_noise_statistics_and_clip_keying():
+    n_per_clip, B = 64 * 1024, 4
+    n = n_per_clip * B
+    zeros = torch.zeros(n, device=DEV)
+    one = torch.ones(1000, device=DEV)
+    zero = torch.zeros(1000, device=DEV)
+    tseq = torch.tensor([5], dtype=torch.int32, device=DEV)
+    step = torch.tensor([0], dtype=torch.int32, device=DEV)
+
+    def draw(clip0, Bn, seed=1234):
+        out = torch.zeros(n_per_clip * Bn, device=DEV)
+        ops.sched_step(0, zeros[: n_per_clip * Bn], zeros[: n_per_clip * Bn], out, n_per_clip * Bn, n_per_clip=n_per_clip,
+                       tseq=tseq, step=step, c1=zero, c2=zero, sigma=one, seed=seed, clip0=clip0)
+        torch.cuda.synchronize()
+        return out.cpu()
+    z = draw(0, B)
+    assert abs(float(z.mean())) < 0.01 and abs(float(z.std()) - 1.0) < 0.01
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.1
+    # a rank that owns clips [2, 4) draws exactly the noise the single-GPU run gives those clips
+    assert torch.equal(draw(2, 2), z[2 * n_per_clip:])
+    assert not torch.equal(draw(0, 1, seed=99), z[:n_per_clip])
+
+
+def test_small_ops():
+    g = torch.Generator().manual_seed(2)
+    # cast / bias_act / add_rows / small_linear
+    a = torch.randn(1000, 256, generator=g)
+    v = torch.randn(256, generator=g)
+    o = torch.zeros(1000, 256, device=DEV)
+    ops.bias_act(a.to(DEV), v.to(DEV), o, 1000, 256, ACT_MISH)
+    assert rel(o, F.mish(a + v)) < 1e-6
+    B, L, d = 3, 10, 256
+    pe, st, em = torch.randn(L, d, generator=g), torch.randn(B, d, generator=g), torch.randn(B, d, generator=g)
+    o = torch.zeros(B * L, d, device=DEV)
+    ops.add_rows(o, B * L, d, pe.to(DEV), 1, L, st.to(DEV), L, B, em.to(DEV), L, B)
+    ref = (pe.unsqueeze(0) + st.unsqueeze(1) + em.unsqueeze(1)).reshape(B * L, d)
+    assert rel(o, ref) < 1e-6
+    x = torch.eye(8)[[2, 5, 2]]
+    Ws, bs = torch.randn(d, 8, generator=g), torch.randn(d, generator=g)
+    o = torch.zeros(3, d, device=DEV)
+    ops.small_linear(x.to(DEV), Ws.to(DEV), bs.to(DEV), o, 3, 8, d)
+    assert rel(o, x @ Ws.t() + bs) < 1e-6
+    # replicate pad / group pad
+    xin = torch.randn(2, 5, 64, generator=g)
+    o = torch.zeros(2, 9, 64, device=DEV)
+    ops.pad_rows(xin.to(DEV), o, 2, 5, 64, 2)
+    ref = F.pad(xin.transpose(1, 2), (2, 2), mode="replicate").transpose(1, 2)
+    assert torch.equal(o.cpu(), ref)
+    o = torch.zeros(4, 2, 5 + 6, 16, device=DEV)
+    ops.group_pad(xin.to(DEV), o, 2, 5, 64, 4, 3)
+    ref = F.pad(xin.view(2, 5, 4, 16).permute(2, 0, 1, 3), (0, 0, 3, 3))
+    assert torch.equal(o.cpu(), ref)
+    # conv0
+    wav = torch.randn(2, 4000, generator=g)
+    w0, b0 = torch.randn(512, 1, 10, generator=g), torch.randn(512, generator=g)
+    T0 = (4000 - 10) // 5 + 1
+    o = torch.zeros(2, T0, 512, device=DEV)
+    ops.conv0(wav.to(DEV), w0.to(DEV), b0.to(DEV), o, 2, 4000, T0)
+    assert rel(o, F.conv1d(wav.unsqueeze(1), w0, b0, stride=5).transpose(1, 2)) < 1e-5
+    # leaky + instance norm
+    xi = torch.randn(2, 37, 1024, generator=g)
+    o = torch.zeros(2, 37, 1024, device=DEV)
+    ops.leaky_instnorm(xi.to(DEV), 2, 37, 1024, y_f32=o)
+    ref = F.instance_norm(F.leaky_relu(xi.transpose(1, 2), 0.2), eps=1e-5).transpose(1, 2)
+    assert rel(o, ref) < 1e-5
+    # adain
+    c, s = torch.randn(12, 11, generator=g), torch.randn(12, 9, generator=g) * 2 + 1
+    o = torch.zeros(12, 11, device=DEV)
+    ops.adain(c.to(DEV), s.to(DEV), o, 12, 11, 9)
+    cm, cs = c.mean(1, keepdim=True), (c.var(1, keepdim=True) + 1e-5).sqrt()
+    sm, ss = s.mean(1, keepdim=True), (s.var(1, keepdim=True) + 1e-5).sqrt()
+    assert rel(o, (c - cm) / cs * ss + sm) < 1e-5
+    torch.cuda.synchronize()
+
+
+def test_program_record_graph_replay():
+    """Record two ops, run eagerly, then replay as a hipGraph with a device-side step counter."""
+    n = 4096
+    x = torch.zeros(n, device=DEV)
+    one = torch.ones(n, device=DEV)
+    tab = torch.arange(1000, dtype=torch.float32, device=DEV)
+    zero = torch.zeros(1000, device=DEV)
+    onev = torch.ones(1000, device=DEV)
+    tseq = torch.arange(10, dtype=torch.int32, device=DEV) * 3
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    prog = ops.Program()
+    with prog:
+        # x <- tab[t] * 1 + 1 * x, t = tseq[step]; step += 1
+        ops.sched_step(0, one, x, x, n, tseq=tseq, step=step, advance=1, c1=tab, c2=onev, sigma=zero, noise=one)
+    assert prog.num_ops == 1
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        prog.run()
+        prog.instantiate()
+        prog.replay(9)
+    s.synchronize()
+    assert int(step[0]) == 10
+    assert float(x[0]) == float(sum(3 * k for k in range(10)))
