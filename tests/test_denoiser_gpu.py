@@ -1,0 +1,135 @@
+"""GPU: the HIP denoiser + scheduler step program against (a) the committed golden vectors produced by
+the reference itself and (b) the CPU oracle on the same seeded inputs.
+
+Tolerances: fp32 (parity) mode 1e-4 max-abs on O(4) latents -- the bar BASELINE.json states;
+bf16 (throughput) mode 8e-2 max-abs per denoiser call (bf16 operands carry 8 significant bits)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from fdm_amd.denoiser import DenoiserPlan  # noqa: E402
+from fdm_amd._lib import BF16, F32  # noqa: E402
+from oracle import fdm_oracle as FO  # noqa: E402
+from oracle import weights as W  # noqa: E402
+
+DEV = "cuda:0"
+TOL32 = 1e-4
+TOLBF = 8e-2
+
+
+def mad(a, b):
+    return float((torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
+
+
+_PLANS = {}
+
+
+def plan_for(preset, dtype):
+    key = (preset, dtype)
+    if key not in _PLANS:
+        _PLANS[key] = (DenoiserPlan(preset, W.make_fdm_weights(preset), dtype, DEV), W.make_fdm_weights(preset))
+    return _PLANS[key]
+
+
+@pytest.mark.parametrize("preset", ["vocaset_tiny", "mead_tiny", "vocaset", "mead"])
+def test_single_step_vs_golden_fp32(golden, preset):
+    g = golden(f"fdm_step_{preset}")
+    plan, _ = plan_for(preset, F32)
+    for (L, t) in g["cases"].tolist():
+        inp = W.synth_inputs(preset, 1, L, seed=100 + L)
+        plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+        out = plan.denoise(inp["x"].to(DEV), t)
+        assert mad(out[0], g[f"x0_L{L}_t{t}"]) < TOL32, (preset, L, t)
+
+
+@pytest.mark.parametrize("preset", ["vocaset", "mead"])
+def test_single_step_bf16_stated_tolerance(golden, preset):
+    g = golden(f"fdm_step_{preset}")
+    plan, _ = plan_for(preset, BF16)
+    for (L, t) in g["cases"].tolist():
+        inp = W.synth_inputs(preset, 1, L, seed=100 + L)
+        plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+        out = plan.denoise(inp["x"].to(DEV), t)
+        assert mad(out[0], g[f"x0_L{L}_t{t}"]) < TOLBF, (preset, L, t)
+
+
+@pytest.mark.parametrize("preset", ["vocaset_tiny", "vocaset", "mead"])
+def test_chains_vs_golden_fp32(golden, preset):
+    """DDPM t=9..0 and 999..990 with injected noise (after every step), DDIM 3 and 50 steps."""
+    g = golden(f"chains_{preset}")
+    plan, _ = plan_for(preset, F32)
+    L = int(g["L"])
+    inp = W.synth_inputs(preset, 1, L, seed=7)
+    plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+    for name in ("lo", "hi"):
+        rec = []
+        noise = torch.from_numpy(g[f"ddpm_{name}_noise"])
+        plan.sample_ddpm(inp["x"].to(DEV), g[f"ddpm_{name}_t"].tolist(), noise=noise, record=rec)
+        assert mad(torch.stack(rec), g[f"ddpm_{name}_steps"]) < TOL32, name
+        # the captured hipGraph gives bit-identical results to eager launches
+        a = plan.sample_ddpm(inp["x"].to(DEV), g[f"ddpm_{name}_t"].tolist(), noise=noise, use_graph=True)
+        b = plan.sample_ddpm(inp["x"].to(DEV), g[f"ddpm_{name}_t"].tolist(), noise=noise, use_graph=False)
+        assert torch.equal(a, b)
+        assert mad(a, g[f"ddpm_{name}_steps"][-1]) < TOL32
+    if "ddim_3_final" in g:
+        for steps in (3, 50):
+            out = plan.sample_ddim(inp["x"].to(DEV), steps)
+            assert mad(out, g[f"ddim_{steps}_final"]) < TOL32, steps
+
+
+def test_cfg_two_pass_mix_vs_golden(golden):
+    g = golden("cfg_mead")
+    plan, _ = plan_for("mead", F32)
+    L, t = int(g["L"]), int(g["t"])
+    inp = W.synth_inputs("mead", 1, L, seed=55)
+    plan.prepare(inp["hub"], inp["style"], inp["emo"], L=L, cfg=True)
+    out = plan.denoise(inp["x"].to(DEV), t, cfg_scale=2.5)
+    assert mad(out[0], g["mix"]) < TOL32
+    assert mad(plan.ws["x0"][plan.M:].reshape(1, -1, 64)[0], g["uncond"]) < TOL32
+
+
+@pytest.mark.parametrize("preset,dtype", [("vocaset", F32), ("mead", F32), ("vocaset", BF16)])
+def test_batched_clips_equal_independent_b1_calls(preset, dtype):
+    """B > 1 == independent B = 1 reference calls; results do not depend on batch composition."""
+    plan, w = plan_for(preset, dtype)
+    B, L, t = 3, 37, 640
+    inp = W.synth_inputs(preset, B, L, seed=21)
+    plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+    out = plan.denoise(inp["x"].to(DEV), t).cpu()
+    ref = FO.fdm_forward(w, preset, inp["hub"], t, inp["x"], inp["style"], inp.get("emo"), folded=True)
+    assert mad(out, ref) < (TOL32 if dtype == F32 else TOLBF)
+    for b in (0, 2):
+        plan.prepare(inp["hub"][b:b + 1], inp["style"][b:b + 1], None if "emo" not in inp else inp["emo"][b:b + 1], L=L)
+        one = plan.denoise(inp["x"][b:b + 1].to(DEV), t).cpu()
+        assert torch.equal(one[0], out[b]), "per-clip result depends on the batch"
+
+
+def test_ddpm_chain_with_device_noise_is_deterministic_and_shardable():
+    """Philox noise is keyed by (seed, global clip index, step): a rank holding clips [1, 3) of a
+    3-clip job reproduces those clips bit for bit."""
+    plan, _ = plan_for("vocaset_tiny", F32)
+    B, L = 3, 20
+    inp = W.synth_inputs("vocaset_tiny", B, L, seed=33)
+    ts = list(range(999, 979, -1))
+    plan.prepare(inp["hub"], inp["style"], L=L)
+    a = plan.sample_ddpm(inp["x"].to(DEV), ts, seed=77).cpu()
+    a2 = plan.sample_ddpm(inp["x"].to(DEV), ts, seed=77).cpu()
+    assert torch.equal(a, a2)
+    plan.prepare(inp["hub"][1:], inp["style"][1:], L=L)
+    s = plan.sample_ddpm(inp["x"][1:].to(DEV), ts, seed=77, clip0=1).cpu()
+    assert torch.equal(s, a[1:])
+    assert torch.isfinite(a).all()
+
+
+def test_long_chain_bf16_stays_close_to_fp32():
+    """Throughput mode: a 50-step DDIM chain in bf16 vs the fp32 plan (stated tolerance 0.15 max-abs)."""
+    L = 24
+    inp = W.synth_inputs("vocaset", 1, L, seed=5)
+    outs = {}
+    for dt in (F32, BF16):
+        plan, _ = plan_for("vocaset", dt)
+        plan.prepare(inp["hub"], inp["style"], L=L)
+        outs[dt] = plan.sample_ddim(inp["x"].to(DEV), 50).cpu()
+    assert mad(outs[F32], outs[BF16]) < 0.15
