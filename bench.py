@@ -1,0 +1,210 @@
+"""bench.py -- animated frames/sec of the FDM diffusion-sampling hot path on N MI355X (one node).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2] [--dtype bf16]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A bench "step" = one full sampling call over this rank's batch of clips (cfg2: B = 4 clips x L = 200
+latent frames, T = 1000 DDPM diffusion steps, in-kernel Philox noise): W untimed calls, then exactly K
+timed calls bracketed by barrier + torch.cuda.synchronize(); max over ranks; rank 0 prints ONE JSON line.
+value = (N * B * L * K) / elapsed = latent frames fully denoised per wall-second (BASELINE.json metric).
+Weak scaling: every rank owns B clips (clip-level batch sharding); the only
+collective is the all-gather of the finished latents, inside the timed region.
+
+roofline: the dominant launch is the captured step graph (one diffusion step).  achieved =
+algorithmic FLOPs per diffusion step (2*[B*L*(2d^2 + n_layers*(4d^2 + 2*d*FFN)) +
+n_layers*B*2*L^2*d]) / average step duration from HIP events recorded on the plan's stream around the
+timed region; peak = dense MFMA bf16 (2.5 PFLOP/s) or fp32 (157.3 TFLOP/s).
+cpu_baseline: the CPU oracle (kind "port") timed on the host cores of this box on a bounded sample of
+the same workload (a few diffusion steps, extrapolated linearly to T), hoisted mode = the same
+arithmetic the GPU path executes; the as-written mode (HuBERT-large re-run inside every step, as
+models/fdm_vocaset.py:59 does) is reported next to it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "face-diffusion-model_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # name: (preset, B per GPU, L, T, sampler, cfg)
+    "cfg1": ("vocaset", 1, 100, 50, "ddim", False),
+    "cfg2": ("vocaset", 4, 200, 1000, "ddpm", False),
+    "cfg3": ("mead", 4, 300, 1000, "ddpm", True),
+}
+PEAK = {"bf16": 2500.0, "f32": 157.3}   # dense TFLOP/s, MI355X_MICROARCH.md
+
+
+def step_flops(p, B, L, cfg):
+    d, nl, ffn = p.d, p.n_layers, p.ffn
+    f = 2.0 * (B * L * (2 * d * d + nl * (4 * d * d + 2 * d * ffn)) + nl * B * 2 * L * L * d)
+    return f * (2 if cfg else 1)
+
+
+def host_threads(cap=32):
+    """Threads the CPU baseline may use: affinity mask and cgroup quota, capped (a 256-thread torch pool on
+    a quota-limited container oversubscribes badly)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(cfg_name, budget_s=24.0):
+    """Bounded sample of the same workload on the host cores (rank 0, N = 1 only)."""
+    from oracle import fdm_oracle as FO
+    from oracle import hubert_oracle as HO
+    from oracle import weights as W
+    preset, B, L, T, sampler, cfg = CONFIGS[cfg_name]
+    cores = host_threads()
+    torch.set_num_threads(cores)
+    w = W.make_fdm_weights(preset)
+    inp = W.synth_inputs(preset, B, L, seed=1)
+    emo = inp.get("emo")
+    buf = FO.schedule_buffers()
+    g = torch.Generator().manual_seed(0)
+    x = inp["x"].clone()
+
+    def hoisted_step(xx, t):
+        x0 = FO.fdm_forward(w, preset, inp["hub"], t, xx, inp["style"], emo, folded=True)
+        if cfg:
+            x0 = FO.cfg_mix(x0, FO.fdm_forward(w, preset, inp["hub"], t, xx, inp["style"], torch.zeros_like(emo), folded=True))
+        return FO.ddpm_step(buf, x0, xx, t, torch.randn(xx.shape, generator=g))
+    # hoisted mode = the arithmetic the GPU path executes; whole diffusion steps until half the budget is spent
+    n, t0 = 0, time.perf_counter()
+    while n < 1 or (time.perf_counter() - t0 < budget_s * 0.5 and n < T):
+        x = hoisted_step(x, T - 1 - n)
+        n += 1
+    per_step = (time.perf_counter() - t0) / n
+    hoisted = B * L / (per_step * T)
+    # as-written mode (models/fdm_vocaset.py:59): HuBERT-large inside every denoiser call, full cross-attention,
+    # clips looped as B = 1 calls.  ONE clip of ONE step is timed and scaled by B (the loop is per clip).
+    t1 = time.perf_counter()
+    wh = W.make_hubert_weights(24)
+    wav = torch.randn(1, L * W.PRESETS[preset]["pair"] * 320 + 80, generator=g) * 0.1
+    t2 = time.perf_counter()
+    hub = HO.hubert_forward(wh, wav, 24)
+    FO.fdm_forward(w, preset, hub, T - 1, x[:1], inp["style"][:1], None if emo is None else emo[:1], folded=False)
+    per_step_aw = (time.perf_counter() - t2) * B * (2 if cfg else 1)
+    return {"value": round(hoisted, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of {T} diffusion steps of the {cfg_name} batch (hoisted+folded fp32 oracle on torch CPU, "
+                      f"{per_step * 1e3:.0f} ms/step), extrapolated linearly to {T} steps; as-written mode (HuBERT-large "
+                      f"re-run in every step, full cross-attention): 1 clip of 1 step timed x{B} clips = "
+                      f"{per_step_aw * 1e3:.0f} ms/step -> {B * L / (per_step_aw * T):.4f} frames/s",
+            "as_written_value": round(B * L / (per_step_aw * T), 5)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+
+    from fdm_amd import presets
+    from fdm_amd._lib import BF16, F32
+    from fdm_amd.denoiser import DenoiserPlan
+    from fdm_amd.parallel import gather_clips
+    from fdm_amd import synth as W
+
+    preset, B, L, T, sampler, cfg = CONFIGS[a.config]
+    p = presets.get(preset)
+    dt = BF16 if a.dtype == "bf16" else F32
+    plan = DenoiserPlan(preset, W.make_fdm_weights(preset), dt, dev)
+    inp = W.synth_inputs(preset, B * world, L, seed=1)      # global batch; this rank owns clips [rank*B, (rank+1)*B)
+    sl = slice(rank * B, (rank + 1) * B)
+    emo = inp["emo"][sl] if "emo" in inp else None
+    plan.prepare(inp["hub"][sl], inp["style"][sl], emo, L=L, cfg=cfg)
+    xT = inp["x"][sl].to(dev)
+    ts = list(range(T - 1, -1, -1))
+
+    def one_call():
+        if sampler == "ddpm":
+            out = plan.sample_ddpm(xT, ts, seed=1234, clip0=rank * B)
+        else:
+            out = plan.sample_ddim(xT, T)
+        return gather_clips(out, dist)
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_call()
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(plan.stream):
+        e0.record(plan.stream)
+    for _ in range(a.steps):
+        out = one_call()
+    with torch.cuda.stream(plan.stream):
+        e1.record(plan.stream)
+    fence()
+    el = time.perf_counter() - t0
+    ev_ms = e0.elapsed_time(e1)
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt[0])
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        n_launch = a.steps * (T if sampler == "ddpm" else T - 1)
+        fl = step_flops(p, B, L, cfg)
+        step_ms = ev_ms / n_launch
+        ach = fl / (step_ms * 1e-3) / 1e12
+        res = {
+            "metric": "animated frames/sec (1000-step DDPM, VOCASET FDM) at 1/2/4/8 MI355X",
+            "value": round(world * B * L * a.steps / el, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"{a.config}: {preset} FDM, {B} clips/GPU x {L} latent frames, {T}-step "
+                                   f"{sampler.upper()}{' + CFG 2.5' if cfg else ''}, random-init weights, "
+                                   f"synthetic HuBERT features, Philox noise", "global_batch": B * world,
+                       "latent_frames": L, "diffusion_steps": T, "parallelism": f"clip-shard x{world}"},
+            "diffusion_steps_per_s": round(n_launch / (ev_ms * 1e-3), 1),
+            "roofline": {"bound": "mfma", "kernel": "denoiser step graph (one diffusion step, all kernels)",
+                         "achieved": round(ach, 2), "peak": PEAK[a.dtype], "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK[a.dtype], 4), "traffic": None,
+                         "flops_per_launch": fl, "avg_launch_ms": round(step_ms, 5)},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(a.config)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

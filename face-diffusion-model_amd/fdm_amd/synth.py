@@ -1,0 +1,182 @@
+"""Seeded synthetic weights and inputs for the FDM path (product side: bench.py, demos, smoke).
+
+There are no checkpoints or datasets in this environment, so benchmarks and demos run on random-init
+weights of the right architecture and synthetic inputs of the right shape.  Each tensor is drawn from
+its own torch.Generator seeded by crc32(name) ^ seed, so the same tensors are produced on any box and
+independently of module construction order.  Names/shapes are the reference state-dict names
+(models/fdm_vocaset.py:17-51, models/fdm_vqvae_mead.py:17-53, models/vq_vae_vocaset.py:194-243,
+models/vq_vae_emotion.py:279-333, transformers HubertModel).  tests/test_synth_cpu.py checks that this
+generator and the oracle's own (oracle/weights.py) produce identical tensors."""
+import math
+import zlib
+from dataclasses import asdict
+
+import torch
+
+from . import presets as _presets
+from .presets import VQ_FFN, VQ_HEADS, VQ_HIDDEN, VQ_LAYERS
+
+
+def _pd(preset):
+    return asdict(_presets.get(preset))
+
+
+def fdm_shapes(preset):
+    """Denoiser parameters excluding `audio_encoder.*` (models/fdm_vocaset.py:20-51)."""
+    p = _pd(preset)
+    d, ffn = p["d"], p["ffn"]
+    s = {
+        "audio_extract.0.weight": (d, p["audio_in"]), "audio_extract.0.bias": (d,),
+        "audio_extract.2.weight": (d, d), "audio_extract.2.bias": (d,),
+        "time_embedd.0.weight": (d, 1000), "time_embedd.0.bias": (d,),
+        "style_embedd.weight": (d, p["n_style"]), "style_embedd.bias": (d,),
+        "latent_encoder.0.weight": (d, d), "latent_encoder.0.bias": (d,),
+        "latent_decoder.weight": (d, d), "latent_decoder.bias": (d,),
+    }
+    if p["n_emo"]:
+        s["emotion_embedd.weight"] = (d, p["n_emo"])
+        s["emotion_embedd.bias"] = (d,)
+    for l in range(p["n_layers"]):
+        pre = f"transformer_decoder.layers.{l}."
+        s[pre + "self_attn.in_proj_weight"] = (3 * d, d)
+        s[pre + "self_attn.in_proj_bias"] = (3 * d,)
+        s[pre + "self_attn.out_proj.weight"] = (d, d)
+        s[pre + "self_attn.out_proj.bias"] = (d,)
+        s[pre + "multihead_attn.in_proj_weight"] = (3 * d, d)
+        s[pre + "multihead_attn.in_proj_bias"] = (3 * d,)
+        s[pre + "multihead_attn.out_proj.weight"] = (d, d)
+        s[pre + "multihead_attn.out_proj.bias"] = (d,)
+        s[pre + "linear1.weight"] = (ffn, d)
+        s[pre + "linear1.bias"] = (ffn,)
+        s[pre + "linear2.weight"] = (d, ffn)
+        s[pre + "linear2.bias"] = (d,)
+        for n in ("norm1", "norm2", "norm3"):
+            s[pre + n + ".weight"] = (d,)
+            s[pre + n + ".bias"] = (d,)
+    return s
+
+
+def hubert_shapes(n_layers=24, hidden=1024, ffn=4096, conv_dim=512):
+    """transformers HubertModel (feat_extract_norm='layer', stable layer norm) parameter names."""
+    kern = (10, 3, 3, 3, 3, 2, 2)
+    s = {"masked_spec_embed": (hidden,)}
+    for i, k in enumerate(kern):
+        pre = f"feature_extractor.conv_layers.{i}."
+        s[pre + "conv.weight"] = (conv_dim, 1 if i == 0 else conv_dim, k)
+        s[pre + "conv.bias"] = (conv_dim,)
+        s[pre + "layer_norm.weight"] = (conv_dim,)
+        s[pre + "layer_norm.bias"] = (conv_dim,)
+    s["feature_projection.layer_norm.weight"] = (conv_dim,)
+    s["feature_projection.layer_norm.bias"] = (conv_dim,)
+    s["feature_projection.projection.weight"] = (hidden, conv_dim)
+    s["feature_projection.projection.bias"] = (hidden,)
+    s["encoder.pos_conv_embed.conv.bias"] = (hidden,)
+    s["encoder.pos_conv_embed.conv.parametrizations.weight.original0"] = (1, 1, 128)
+    s["encoder.pos_conv_embed.conv.parametrizations.weight.original1"] = (hidden, hidden // 16, 128)
+    s["encoder.layer_norm.weight"] = (hidden,)
+    s["encoder.layer_norm.bias"] = (hidden,)
+    for l in range(n_layers):
+        pre = f"encoder.layers.{l}."
+        for n in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            s[pre + f"attention.{n}.weight"] = (hidden, hidden)
+            s[pre + f"attention.{n}.bias"] = (hidden,)
+        s[pre + "layer_norm.weight"] = (hidden,)
+        s[pre + "layer_norm.bias"] = (hidden,)
+        s[pre + "feed_forward.intermediate_dense.weight"] = (ffn, hidden)
+        s[pre + "feed_forward.intermediate_dense.bias"] = (ffn,)
+        s[pre + "feed_forward.output_dense.weight"] = (hidden, ffn)
+        s[pre + "feed_forward.output_dense.bias"] = (hidden,)
+        s[pre + "final_layer_norm.weight"] = (hidden,)
+        s[pre + "final_layer_norm.bias"] = (hidden,)
+    return s
+
+
+def vq_shapes(preset, hidden=VQ_HIDDEN, n_layers=VQ_LAYERS, ffn=VQ_FFN):
+    """Quantizer + decoder parameters (encoder.* is training-only, out of scope)."""
+    p = _pd(preset)
+    s = {"quantize.embedding.weight": (p["K"] * p["n_books"], p["c"]),
+         "decoder.expander.0.0.weight": (hidden, hidden, 5),
+         "decoder.expander.0.0.bias": (hidden,),
+         "decoder.decoder_linear_embedding.net.weight": (hidden, hidden),
+         "decoder.decoder_linear_embedding.net.bias": (hidden,),
+         "decoder.vertice_map_reverse.weight": (p["V3"], hidden)}
+    if p["vq_out_bias"]:
+        s["decoder.vertice_map_reverse.bias"] = (p["V3"],)
+    if p["vq_pre"]:
+        s["decoder.decoder_linear_embedding_pre.net.weight"] = (hidden, p["G"] * p["c"])
+        s["decoder.decoder_linear_embedding_pre.net.bias"] = (hidden,)
+    for l in range(n_layers):
+        a = f"decoder.decoder_transformer.net.{2 * l}.fn."
+        m = f"decoder.decoder_transformer.net.{2 * l + 1}.fn."
+        s[a + "norm.weight"] = (hidden,)
+        s[a + "norm.bias"] = (hidden,)
+        s[a + "fn.to_qkv.weight"] = (3 * hidden, hidden)
+        s[a + "fn.to_out.weight"] = (hidden, hidden)
+        s[a + "fn.to_out.bias"] = (hidden,)
+        s[m + "norm.weight"] = (hidden,)
+        s[m + "norm.bias"] = (hidden,)
+        s[m + "fn.l1.weight"] = (ffn, hidden)
+        s[m + "fn.l1.bias"] = (ffn,)
+        s[m + "fn.l2.weight"] = (hidden, ffn)
+        s[m + "fn.l2.bias"] = (hidden,)
+    return s
+
+
+def _is_norm(name):
+    return ("norm" in name) and ("to_" not in name)
+
+
+def make_weights(shapes, seed=0, prefix=""):
+    """name -> fp32 tensor.  Matrices ~ N(0, 1/fan_in) so activations stay O(1); biases N(0, 0.02);
+    LayerNorm weights 1 + N(0, 0.1); codebooks U(-1/K, 1/K) as in models/lib/quantizer.py:33."""
+    out = {}
+    for name, shape in shapes.items():
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)
+        if name.endswith("embedding.weight") and name.startswith("quantize"):
+            k = shape[0]
+            k = 256 if k % 256 == 0 else k
+            w = (torch.rand(shape, generator=g) * 2 - 1) / k
+        elif name.endswith("original0"):
+            w = 1.0 + 0.25 * torch.rand(shape, generator=g)
+        elif _is_norm(name) and name.endswith("weight"):
+            w = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif _is_norm(name) and name.endswith("bias"):
+            w = 0.05 * torch.randn(shape, generator=g)
+        elif name.endswith("bias") or name.endswith("in_proj_bias") or len(shape) == 1:
+            w = 0.02 * torch.randn(shape, generator=g)
+        else:
+            fan_in = 1
+            for s_ in shape[1:]:
+                fan_in *= s_
+            w = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+        out[prefix + name] = w.float().contiguous()
+    return out
+
+
+def make_fdm_weights(preset, seed=0):
+    return make_weights(fdm_shapes(preset), seed)
+
+
+def make_hubert_weights(n_layers=24, seed=0, prefix=""):
+    return make_weights(hubert_shapes(n_layers), seed, prefix)
+
+
+def make_vq_weights(preset, seed=0):
+    return make_weights(vq_shapes(preset), seed)
+
+
+def synth_inputs(preset, B, L, seed=1, audio_frames=None):
+    """Seeded synthetic inputs: hubert features, x_T, one-hots.
+
+    Returns a dict of CPU tensors; `hub` stands in for HubertModel(audio).last_hidden_state
+    ([B, N, 1024]) so that denoiser cases do not depend on the audio encoder."""
+    p = _pd(preset)
+    g = torch.Generator().manual_seed(seed)
+    n = audio_frames if audio_frames is not None else L * p["pair"]
+    hub = torch.randn(B, n, 1024, generator=g)
+    x = torch.randn(B, L * p["G"], p["c"], generator=g)
+    sid = torch.eye(p["n_style"])[torch.arange(B) % p["n_style"]]
+    out = dict(hub=hub, x=x, style=sid)
+    if p["n_emo"]:
+        out["emo"] = torch.eye(p["n_emo"])[torch.arange(B) % p["n_emo"]]
+    return out
