@@ -1,0 +1,129 @@
+"""(E)VQ-VAE quantise + decode on the HIP path.
+
+quant : models/lib/quantizer.py:35-64, models/vq_vae_emotion.py:221-252 -> fdm_op_vq_quant
+decode: models/vq_vae_vocaset.py:35-43,245-258 / models/vq_vae_emotion.py:33-41,335-352 /
+        models/vq_vae.py:275-347 with models/lib/base_models.py:37-87,138-174,286-301:
+  [decoder_linear_embedding_pre GEMM]                       (MEAD / BIWI only)
+  Conv1d(1024, 1024, k=5, replicate pad)   fdm_op_pad_rows + fdm_op_gemm with overlapping rows (K = 5*1024)
+  LeakyReLU(0.2) + InstanceNorm1d          fdm_op_leaky_instnorm
+  Linear + pe[0] (the reference indexes the positional table by batch position, base_models.py:300;
+                  bs = 1 usage == pe[0] for every clip)   fdm_op_gemm, row-broadcast residual
+  6 x pre-LN {attention (scale = hidden^-0.5, base_models.py:144), tanh-GELU MLP}
+  Linear(1024, V3)                         fdm_op_gemm (N = 15069 / 70110, unaligned rows handled)
+"""
+import math
+
+import torch
+
+from . import ops, presets
+from ._lib import ACT_GELU_TANH, ACT_NONE, BF16, F32, FdmError
+from .presets import VQ_FFN, VQ_HEADS, VQ_HIDDEN, VQ_LAYERS
+
+
+class VQPlan:
+    def __init__(self, preset, weights, dtype=F32, device="cuda:0"):
+        self.p = presets.get(preset)
+        self.dtype, self.td = dtype, ops.tdtype(dtype)
+        self.device = dv = torch.device(device)
+        self.stream = torch.cuda.Stream(device=dv)
+        g = lambda k: weights[k].detach().to(device=dv, dtype=torch.float32).contiguous()
+        p, d = self.p, VQ_HIDDEN
+        with torch.cuda.stream(self.stream):
+            op = lambda t: ops.to_operand(t.contiguous(), dtype)
+            self.codebook = g("quantize.embedding.weight")
+            if self.codebook.shape != (p.K * p.n_books, p.c):
+                raise FdmError(f"codebook shape {tuple(self.codebook.shape)} != {(p.K * p.n_books, p.c)}")
+            self.pre = None
+            if p.vq_pre:
+                self.pre = (op(g("decoder.decoder_linear_embedding_pre.net.weight")), g("decoder.decoder_linear_embedding_pre.net.bias"))
+            wc = g("decoder.expander.0.0.weight")                                   # [1024, 1024, 5]
+            self.conv_w = op(wc.permute(0, 2, 1).reshape(d, 5 * d))                  # [out, (k, in)]
+            self.conv_b = g("decoder.expander.0.0.bias")
+            self.emb = (op(g("decoder.decoder_linear_embedding.net.weight")), g("decoder.decoder_linear_embedding.net.bias"))
+            pe0 = torch.zeros(d)
+            pe0[1::2] = 1.0                                                          # sin(0) = 0, cos(0) = 1
+            self.pe0 = pe0.to(dv).view(1, d)
+            self.layers = []
+            for l in range(VQ_LAYERS):
+                a = f"decoder.decoder_transformer.net.{2 * l}.fn."
+                m = f"decoder.decoder_transformer.net.{2 * l + 1}.fn."
+                self.layers.append(dict(
+                    ln1=(g(a + "norm.weight"), g(a + "norm.bias")), wqkv=op(g(a + "fn.to_qkv.weight")),
+                    wo=op(g(a + "fn.to_out.weight")), bo=g(a + "fn.to_out.bias"),
+                    ln2=(g(m + "norm.weight"), g(m + "norm.bias")),
+                    w1=op(g(m + "fn.l1.weight")), b1=g(m + "fn.l1.bias"), w2=op(g(m + "fn.l2.weight")), b2=g(m + "fn.l2.bias")))
+            self.out_w = op(g("decoder.vertice_map_reverse.weight"))
+            self.out_b = g("decoder.vertice_map_reverse.bias") if "decoder.vertice_map_reverse.bias" in weights else None
+        self.stream.synchronize()
+
+    # ------------------------------------------------------------------------------------------
+    def quant(self, z, emo=None):
+        """z [B, R, c] fp32 -> (z_q [B, c, R] fp32, idx [B*R, 1] int64), book chosen by argmax(one_hot)."""
+        p, dv = self.p, self.device
+        z = z.detach().to(device=dv, dtype=torch.float32).contiguous()
+        B, R, c = z.shape
+        if c != p.c:
+            raise FdmError(f"latent width {c} != zquant_dim {p.c}")
+        book = None
+        if p.n_books > 1:
+            if emo is None:
+                raise FdmError("this preset needs the emotion one-hot to pick the codebook slice")
+            emo = emo.to(dv)
+            if emo.dim() == 1:
+                emo = emo.unsqueeze(0).expand(B, -1)
+            book = torch.argmax(emo, dim=1).to(torch.int32).contiguous()
+        zq = torch.empty(B, c, R, device=dv)
+        idx = torch.empty(B * R, 1, device=dv, dtype=torch.int64)
+        ops.vq_quant(z, self.codebook, book, B, R, c, p.K, zq, idx)
+        return zq, idx
+
+    def decode(self, zq):
+        """zq [B, c, L*G] -> vertex offsets [B, L, V3] fp32 (template is added by the caller)."""
+        p, dv, td, dt, d = self.p, self.device, self.td, self.dtype, VQ_HIDDEN
+        B, c, R = zq.shape
+        if c != p.c or R % p.G:
+            raise FdmError(f"bad quantised latent shape {tuple(zq.shape)}")
+        L = R // p.G
+        if L < 2:
+            raise FdmError("decode needs at least 2 frames (InstanceNorm1d over one element is undefined in the reference)")
+        M = B * L
+        H, hd = VQ_HEADS, d // VQ_HEADS
+        z = lambda *s, dtp=torch.float32: torch.empty(*s, device=dv, dtype=dtp)
+        cur = torch.cuda.current_stream(dv)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            x = zq.detach().to(device=dv, dtype=torch.float32).permute(0, 2, 1).reshape(M, p.G * p.c).contiguous()   # layout only
+            xt = ops.to_operand(x, dt)
+            if self.pre is not None:
+                y = z(M, d, dtp=td)
+                ops.gemm(xt, self.pre[0], M, d, p.G * p.c, bias=self.pre[1], out_t=y)
+                xt = y
+            elif p.G * p.c != d:
+                raise FdmError("decoder input width must equal hidden size when there is no pre-embedding")
+            xp = z(B, L + 4, d, dtp=td)
+            ops.pad_rows(xt, xp, B, L, d, 2)
+            c32 = z(M, d)
+            ops.gemm(xp, self.conv_w, L, d, 5 * d, lda=d, bias=self.conv_b, out_f32=c32, batch=B, a_bs=(L + 4) * d, out_bs=L * d)
+            nt = z(M, d, dtp=td)
+            ops.leaky_instnorm(c32, B, L, d, y_t=nt, dtype=dt)
+            h = z(M, d)
+            ops.gemm(nt, self.emb[0], M, d, d, bias=self.emb[1], resid=self.pe0, ldr=d, resid_row_mod=1, out_f32=h)
+            Lpad = (L + 31) // 32 * 32
+            qkv = z(M, 3 * d, dtp=td)
+            vt = torch.zeros(B * H, hd, Lpad, device=dv, dtype=td)
+            ctx, u, hb = z(M, d, dtp=td), z(M, VQ_FFN, dtp=td), z(M, d)
+            a = z(M, d, dtp=td)
+            for ly in self.layers:
+                ops.layernorm(h, ly["ln1"][0], ly["ln1"][1], M, d, y_t=a, dtype=dt)
+                ops.gemm(a, ly["wqkv"], M, 3 * d, d, out_t=qkv, ldo_t=3 * d, out_vt=vt, vt_col0=2 * d, vt_L=L, vt_Lpad=Lpad, vt_hd=hd)
+                ops.attention(qkv, qkv[:, d:], vt, ctx, B=B, H=H, L=L, hd=hd, ldq=3 * d, ldk=3 * d, ldo=d, Lpad=Lpad,
+                              scale=d ** -0.5, causal=False)
+                ops.gemm(ctx, ly["wo"], M, d, d, bias=ly["bo"], resid=h, out_f32=hb)
+                ops.layernorm(hb, ly["ln2"][0], ly["ln2"][1], M, d, y_t=a, dtype=dt)
+                ops.gemm(a, ly["w1"], M, VQ_FFN, d, bias=ly["b1"], act=ACT_GELU_TANH, out_t=u)
+                ops.gemm(u, ly["w2"], M, d, VQ_FFN, bias=ly["b2"], resid=hb, out_f32=h)
+            ht = ops.to_operand(h, dt)
+            out = z(M, p.V3)
+            ops.gemm(ht, self.out_w, M, p.V3, d, bias=self.out_b, out_f32=out)
+        cur.wait_stream(self.stream)
+        return out.view(B, L, p.V3)
