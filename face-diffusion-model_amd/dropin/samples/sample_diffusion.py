@@ -1,0 +1,54 @@
+"""Test-set style sampler -- the loop of /root/reference samples/sample_diffusion_{vocaset,mead,biwi}.py
+(sample_step :59-88 / :67-86 / :60-78) over any iterable of (audio, template, one_hots, file_name); without
+the datasets (not available here) it runs on seeded synthetic clips.
+
+    python sample_diffusion.py --dataset vocaset --clips 2 --seconds 2 --ddim_steps 100 --out result/
+"""
+import argparse
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _path  # noqa: F401,E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from fdm_amd import pipeline, presets  # noqa: E402
+
+
+def synthetic_loader(p, clips, seconds, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    for i in range(clips):
+        wav = pipeline.processor_normalize((torch.randn(int(seconds * 16000), generator=g) * 0.1).numpy(), pad_seconds=0)
+        yield torch.from_numpy(wav).unsqueeze(0), torch.zeros(1, p.V3), torch.eye(p.n_style).unsqueeze(0), f"synthetic_{i:03d}.wav"
+
+
+@torch.no_grad()
+def sample_step(loader, dev, diffusion, autoencoder, save_folder, p, ddim_steps, emotion=4, all_styles=False):
+    os.makedirs(save_folder, exist_ok=True)
+    for audio, template, one_hot_all, file_name in loader:
+        styles = range(one_hot_all.shape[1]) if all_styles else [0]
+        for it in styles:                                               # samples/sample_diffusion_vocaset.py:71
+            id_one_hot = one_hot_all[:, it, :]
+            emo = torch.eye(p.n_emo)[emotion:emotion + 1] if p.n_emo else None
+            out, _ = pipeline.animate(diffusion, autoencoder, audio, template, id_one_hot, emo,
+                                      ddim_steps=None if p.n_emo else ddim_steps, device=dev)
+            dst = os.path.join(save_folder, f"{file_name[:-4]}_condition_{it}")
+            np.save(dst, out.detach().cpu().numpy())
+            print(f"saved {dst}.npy {tuple(out.shape)}")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dataset", default="vocaset", choices=["vocaset", "mead", "biwi"])
+    ap.add_argument("--clips", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=2.0)
+    ap.add_argument("--ddim_steps", type=int, default=100)      # VOCASET ships DDIM 100, BIWI DDIM 50, MEAD full DDPM
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--out", default="result")
+    ap.add_argument("--stage1_model_path", default="")
+    ap.add_argument("--stage2_model_path", default="")
+    a = ap.parse_args()
+    p = presets.get(a.dataset)
+    diffusion, ae = pipeline.build_models(a.dataset, None, a.device, a.stage1_model_path, a.stage2_model_path)
+    sample_step(synthetic_loader(p, a.clips, a.seconds), a.device, diffusion, ae, a.out, p, a.ddim_steps)

@@ -1,0 +1,394 @@
+"""Host-side mirror of the reference's Python class surface (the drop-in boundary).
+
+Same class names, constructor arguments, method names, argument order, tensor shapes and state-dict
+keys as the reference, so that a reference checkpoint loads and the reference's callers
+(samples/sample_diffusion_*.py, demo/demo_*.py) run unchanged -- but every forward pass executes on
+the HIP path (fdm_amd.denoiser / hubert / vq through libfdm_hip.so).  There is no CPU fallback:
+calling forward on CPU tensors raises.
+
+  FDM (VOCASET)          models/fdm_vocaset.py:8-91
+  FDM (3D-MEAD)          models/fdm_vqvae_mead.py:8-104
+  FDM (BIWI)             models/fdm.py:9-99        (struct='Dec' + regroup x8: build-defined)
+  GaussianDiffusion      video_diffusion_pytorch/diffusion_BIWI_encoder_decoder.py:549-761,
+                         video_diffusion_pytorch/diffusion_mead_encoder_decoder.py:641-671
+  HubertModel            models/hubert.py:72-146
+  VQAutoEncoder          models/vq_vae_vocaset.py:9-43, models/vq_vae_emotion.py:9-41, models/vq_vae.py
+  ClassifierFreeSampleModel  utiles/classifierfree.py:8-21
+"""
+import math
+import os
+from dataclasses import replace
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import presets, schedule, synth
+from ._lib import BF16, F32, FdmError
+from .denoiser import DenoiserPlan
+from .hubert import HubertPlan, num_frames
+from .vq import VQPlan
+
+
+def compute_dtype(name=None):
+    name = name or os.environ.get("FDM_AMD_DTYPE", "fp32")
+    return BF16 if name.lower() in ("bf16", "bfloat16") else F32
+
+
+class ParamTree(nn.Module):
+    """Registers parameters/buffers under dotted names so state_dict keys equal the reference's."""
+
+    def _register(self, name, tensor, buffer=False):
+        mod = self
+        parts = name.split(".")
+        for part in parts[:-1]:
+            if part not in mod._modules:
+                mod.add_module(part, nn.Module())
+            mod = mod._modules[part]
+        if buffer:
+            mod.register_buffer(parts[-1], tensor)
+        else:
+            mod.register_parameter(parts[-1], nn.Parameter(tensor, requires_grad=False))
+
+    def _load_from_state_dict(self, *a, **k):
+        self._plan_stale = True
+        return super()._load_from_state_dict(*a, **k)
+
+
+def _tensor_key(t):
+    return None if t is None else (t.data_ptr(), tuple(t.shape), t._version, str(t.device))
+
+
+# --------------------------------------------------------------------------------------------------
+class HubertModel(ParamTree):
+    """HuBERT-large (24 layers) with the reference's forward override; `from_pretrained` loads a local
+    HF checkpoint directory when present, else keeps the seeded random init (no network here)."""
+
+    def __init__(self, config=None, n_layers=24, seed=0, dtype=None):
+        super().__init__()
+        self.n_layers = int(getattr(config, "num_hidden_layers", n_layers)) if config is not None else n_layers
+        self.config = config or SimpleNamespace(num_hidden_layers=self.n_layers, hidden_size=1024, output_attentions=False)
+        for k, v in synth.make_hubert_weights(self.n_layers, seed).items():
+            self._register(k, v)
+        self.feature_extractor._freeze_parameters = lambda: None      # models/fdm_vocaset.py:19
+        self._dtype = compute_dtype(dtype)
+        self._plan = None
+        self._plan_stale = True
+
+    @classmethod
+    def from_pretrained(cls, path=None, *a, **k):
+        m = cls()
+        if path and os.path.isdir(str(path)):
+            for fn in ("model.safetensors", "pytorch_model.bin"):
+                fp = os.path.join(str(path), fn)
+                if os.path.exists(fp):
+                    if fn.endswith(".safetensors"):
+                        from safetensors.torch import load_file
+                        sd = load_file(fp)
+                    else:
+                        sd = torch.load(fp, map_location="cpu")
+                    sd = {kk[len("hubert."):] if kk.startswith("hubert.") else kk: vv for kk, vv in sd.items()}
+                    sd = {kk.replace("conv.weight_g", "conv.parametrizations.weight.original0")
+                            .replace("conv.weight_v", "conv.parametrizations.weight.original1"): vv for kk, vv in sd.items()}
+                    m.load_state_dict(sd, strict=False)
+                    break
+        return m
+
+    def _get_plan(self, device):
+        if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
+            self._plan = HubertPlan(self.state_dict(), self.n_layers, self._dtype, device)
+            self._plan_stale = False
+        return self._plan
+
+    def forward(self, input_values, attention_mask=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, frame_num=None):
+        if not input_values.is_cuda:
+            raise FdmError("HubertModel.forward runs on the HIP path only: move the audio to the GPU")
+        # a `str` second positional argument (models/fdm_vocaset.py:59 passes 'vocaset') is ignored
+        out = self._get_plan(input_values.device).forward(input_values)
+        if frame_num and out.shape[1] > frame_num * 2:
+            out = out[:, : frame_num * 2]
+        return SimpleNamespace(last_hidden_state=out, hidden_states=None, attentions=None)
+
+
+# --------------------------------------------------------------------------------------------------
+class _FDMBase(ParamTree):
+    preset_name = "vocaset"
+
+    def _build(self, feature_dim, n_head, num_layers, struct, dtype, audio_encoder=True):
+        base = presets.get(self.preset_name)
+        self.preset = replace(base, name=f"{base.name}_d{feature_dim}", d=feature_dim, n_head=n_head, n_layers=num_layers,
+                              ffn=2 * feature_dim, c=feature_dim // base.G)
+        if self.preset.head_dim != 128:
+            raise FdmError(f"feature_dim/n_head = {self.preset.head_dim}: the HIP attention kernel supports head_dim 128")
+        self.struct = struct
+        presets.PRESETS[self.preset.name] = self.preset
+        for k, v in synth.make_fdm_weights(self.preset.name).items():
+            self._register(k, v)
+        # nn.init.constant_(latent_decoder.*, 0)  (models/fdm_vocaset.py:50-51)
+        self.latent_decoder.weight.data.zero_()
+        self.latent_decoder.bias.data.zero_()
+        n_pe = 630 if self.preset.pe == "periodic" else 5000
+        self._register("PE.pe", schedule.positional_table(feature_dim, self.preset.pe, self.preset.period, n_pe).unsqueeze(0), buffer=True)
+        self.audio_encoder = HubertModel.from_pretrained("/data/WX/hubert-large-ls960-ft") if audio_encoder else None
+        self.one_hot_timesteps = None
+        self._dtype = compute_dtype(dtype)
+        self._plan = None
+        self._plan_stale = True
+        self._prep_key = None
+        self._hub_key, self._hub = None, None
+
+    # -- plan management --------------------------------------------------------------------
+    def plan(self, device):
+        if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
+            sd = {k: v for k, v in self.state_dict().items() if not k.startswith("audio_encoder.")}
+            self._plan = DenoiserPlan(self.preset, sd, self._dtype, device)
+            self._plan_stale = False
+            self._prep_key = None
+        return self._plan
+
+    def set_audio_features(self, hub):
+        """Inject precomputed HuBERT features [B, N, 1024] (bypasses the audio encoder)."""
+        self._hub_key, self._hub = "injected", hub
+
+    def audio_features(self, audio):
+        if self._hub_key == "injected":
+            return self._hub
+        key = _tensor_key(audio)
+        if key != self._hub_key:      # step-invariant: computed once per audio tensor (hoisted, exact)
+            self._hub = self.audio_encoder(audio).last_hidden_state
+            self._hub_key = key
+        return self._hub
+
+    def prepare(self, audio, L, style, emo=None, cfg=False):
+        hub = self.audio_features(audio)
+        plan = self.plan(hub.device)
+        key = (self._hub_key if self._hub_key != "injected" else _tensor_key(hub), L, bool(cfg),
+               tuple(style.flatten().tolist()), None if emo is None else tuple(emo.flatten().tolist()))
+        if key != self._prep_key:
+            B = hub.shape[0]
+            st = style.reshape(-1, style.shape[-1])
+            em = None if emo is None else emo.reshape(-1, emo.shape[-1])
+            plan.prepare(hub, st if st.shape[0] == B else st[0], em if (em is None or em.shape[0] == B) else em[0], L=L, cfg=cfg)
+            self._prep_key = key
+        return plan
+
+    def _forward(self, audio, t, vertice, style, emo=None):
+        if not vertice.is_cuda:
+            raise FdmError("FDM.forward runs on the HIP path only: move inputs to the GPU")
+        G = self.preset.G
+        L = vertice.shape[1] // G
+        hub = self.audio_features(audio)
+        nf = min(hub.shape[1] // self.preset.pair, L)                 # models/fdm_vocaset.py:64-66
+        plan = self.prepare(audio, nf, style, emo)
+        tt = int(t.flatten()[0]) if torch.is_tensor(t) else int(t)
+        x = vertice.reshape(vertice.shape[0], L, G * vertice.shape[2])[:, :nf].reshape(vertice.shape[0], nf * G, -1)
+        return plan.denoise(x.contiguous().float(), tt)
+
+
+class FDM(_FDMBase):
+    """VOCASET denoiser: FDM(feature_dim=512, n_head=8, num_layers=8, struct='Enc')."""
+    preset_name = "vocaset"
+
+    def __init__(self, feature_dim=512, n_head=8, num_layers=8, struct="Enc", dtype=None, audio_encoder=True):
+        super().__init__()
+        self._build(feature_dim, n_head, num_layers, struct, dtype, audio_encoder)
+
+    def forward(self, audio, t, vertice, id_one_hot):
+        return self._forward(audio, t, vertice, id_one_hot)
+
+
+class FDMMead(_FDMBase):
+    """3D-MEAD denoiser: FDM(feature_dim=512, vertice_dim=70110, n_head=4, num_layers=8, struct='Enc')."""
+    preset_name = "mead"
+
+    def __init__(self, feature_dim=512, vertice_dim=70110, n_head=4, num_layers=8, struct="Enc", dtype=None, audio_encoder=True):
+        super().__init__()
+        self._build(feature_dim, n_head, num_layers, struct, dtype, audio_encoder)
+
+    def mask_cond(self, cond, train=False, force_mask=False):          # models/fdm_vqvae_mead.py:54-62
+        if force_mask:
+            return torch.zeros_like(cond)
+        if train:
+            mask = torch.bernoulli(torch.ones_like(cond) * 0.1)
+            return cond * (1.0 - mask)
+        return cond
+
+    def forward(self, audio, t, vertice, emotion_one_hot, id_one_hot, mask_cond=False, train=True):
+        emo = self.mask_cond(emotion_one_hot.reshape(-1, emotion_one_hot.shape[-1]), force_mask=bool(mask_cond))
+        return self._forward(audio, t, vertice, id_one_hot, emo)
+
+
+class FDMBiwi(_FDMBase):
+    """BIWI denoiser (build-defined semantics: 'Dec' struct, latent regrouped x8; parity unpinned vs reference)."""
+    preset_name = "biwi"
+
+    def __init__(self, feature_dim=1024, vertice_dim=70110, n_head=8, num_layers=8, struct="Dec", dtype=None, audio_encoder=False):
+        super().__init__()
+        self._build(feature_dim, n_head, num_layers, struct, dtype, audio_encoder)
+
+    def forward(self, audio, t, vertice, id_one_hot):
+        return self._forward(audio, t, vertice, id_one_hot)
+
+
+class ClassifierFreeSampleModel(nn.Module):
+    """out_uncond + level * (out - out_uncond) (utiles/classifierfree.py:15-21), wired to the MEAD FDM:
+    the unconditional pass zeroes the emotion one-hot; both passes run as one batched
+    step program and the mix is fused into the scheduler kernel."""
+
+    def __init__(self, model, level=2.5):
+        super().__init__()
+        self.model, self.level = model, level
+
+    def forward(self, audio, t, x_noisy, emotion_one_hot, id_one_hot):
+        m = self.model
+        L = x_noisy.shape[1] // m.preset.G
+        plan = m.prepare(audio, L, id_one_hot, emotion_one_hot.reshape(-1, emotion_one_hot.shape[-1]), cfg=True)
+        tt = int(t.flatten()[0]) if torch.is_tensor(t) else int(t)
+        return plan.denoise(x_noisy.contiguous().float(), tt, cfg_scale=self.level)
+
+
+# --------------------------------------------------------------------------------------------------
+class GaussianDiffusion(nn.Module):
+    """Sampling surface of the reference's GaussianDiffusion.  One class serves both reference variants:
+    conditions are passed through (*cond) = (id_one_hot,) for VOCASET/BIWI, (emo_one_hot, id_one_hot) for MEAD.
+
+    Build-added keyword inputs (default None => reference behaviour): noise= (x_T and per-step z for
+    parity runs), seed=, t_range=, guidance_scale=."""
+
+    def __init__(self, denoise_fn, *, text_use_bert_cls=False, channels=3, timesteps=1000, loss_type="l1",
+                 use_dynamic_thres=False, dynamic_thres_percentile=0.9):
+        super().__init__()
+        self.channels, self.denoise_fn = channels, denoise_fn
+        self.num_timesteps, self.loss_type = int(timesteps), loss_type
+        self.text_use_bert_cls, self.use_dynamic_thres = text_use_bert_cls, use_dynamic_thres
+        self.dynamic_thres_percentile = dynamic_thres_percentile
+        for k, v in schedule.make_buffers(timesteps).items():
+            self.register_buffer(k, v)
+        self.full_chain = True     # False reproduces the VOCASET variant's hard-coded t = 999..500 (:663-665)
+
+    # -- small exact host-side pieces kept for API completeness ---------------------------------
+    @staticmethod
+    def _extract(a, t, x_shape):
+        out = a.gather(-1, t)
+        return out.reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+    def predict_noise_from_start(self, x_t, t, x0):
+        return (self._extract(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t - x0) / \
+            self._extract(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape)
+
+    def q_posterior(self, x_start, x_t, t):
+        mean = self._extract(self.posterior_mean_coef1, t, x_t.shape) * x_start + \
+            self._extract(self.posterior_mean_coef2, t, x_t.shape) * x_t
+        return mean, self._extract(self.posterior_variance, t, x_t.shape), \
+            self._extract(self.posterior_log_variance_clipped, t, x_t.shape)
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = torch.randn_like(x_start) if noise is None else noise
+        return self._extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start + \
+            self._extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise
+
+    def _split_cond(self, cond):
+        m = self.denoise_fn
+        model = m.model if isinstance(m, ClassifierFreeSampleModel) else m
+        if model.preset.n_emo:
+            emo, style = cond
+            return model, style, emo.reshape(-1, emo.shape[-1])
+        return model, cond[0], None
+
+    def _plan(self, audio, shape, cond, guidance_scale=None):
+        model, style, emo = self._split_cond(cond)
+        cfg = isinstance(self.denoise_fn, ClassifierFreeSampleModel) or guidance_scale is not None
+        scale = guidance_scale if guidance_scale is not None else getattr(self.denoise_fn, "level", 2.5)
+        L = shape[1] // model.preset.G
+        return model.prepare(audio, L, style, emo, cfg=cfg), scale
+
+    @torch.no_grad()
+    def p_mean_variance(self, x, t, clip_denoised, audio, *cond):
+        x_recon = self.denoise_fn(audio, t, x, *cond)
+        return self.q_posterior(x_start=x_recon, x_t=x, t=t)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, audio, *cond, clip_denoised=False, noise=None):
+        """One reverse step on the HIP path (denoiser + fused scheduler update)."""
+        plan, scale = self._plan(audio, x.shape, cond)
+        tt = int(t.flatten()[0])
+        z = noise if noise is not None else torch.randn_like(x)
+        return plan.sample_ddpm(x.float().contiguous(), [tt], noise=z.reshape(1, *x.shape), cfg_scale=scale, use_graph=False)
+
+    @torch.no_grad()
+    def p_sample_loop(self, shape, audio, *cond, noise=None, seed=None, t_range=None, guidance_scale=None):
+        plan, scale = self._plan(audio, shape, cond, guidance_scale)
+        dev = plan.device
+        if t_range is None:
+            t_range = (self.num_timesteps - 1, -1) if self.full_chain else (999, 499)
+        ts = list(range(t_range[0], t_range[1], -1))
+        if noise is not None:
+            x_T, z = noise[0].to(dev), noise[1]
+            return plan.sample_ddpm(x_T.float().contiguous(), ts, noise=z, cfg_scale=scale)
+        x_T = torch.randn(shape, device=dev)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if seed is None else int(seed)
+        return plan.sample_ddpm(x_T, ts, seed=seed, cfg_scale=scale)
+
+    @torch.no_grad()
+    def sample(self, audio, latent_motion_shape, *cond, **kw):
+        return self.p_sample_loop(latent_motion_shape, audio, *cond, **kw)
+
+    @torch.no_grad()
+    def ddim_sample(self, audio, latent_motion_shape, id_one_hot, steps=500, *, x_T=None, guidance_scale=None):
+        plan, scale = self._plan(audio, latent_motion_shape, (id_one_hot,), guidance_scale)
+        x_T = torch.randn(latent_motion_shape, device=plan.device) if x_T is None else x_T.to(plan.device)
+        return plan.sample_ddim(x_T.float().contiguous(), steps, cfg_scale=scale)
+
+    def forward(self, *a, **k):
+        raise FdmError("training (p_losses / backward) is out of scope of the sampling hot path (SURVEY.md section 2, row 22)")
+
+
+# --------------------------------------------------------------------------------------------------
+class VQAutoEncoder(ParamTree):
+    """quant + decode of the (E)VQ-VAE; `args` as returned by models/utils/config.py helpers."""
+
+    def __init__(self, args, dtype=None):
+        super().__init__()
+        self.args = args
+        if args.in_dim == 70110:
+            base = presets.BIWI
+        elif args.n_embed > 256:
+            base = presets.MEAD
+        else:
+            base = presets.VOCASET
+        self.preset = replace(base, name=f"vq_{base.name}_{args.in_dim}_{args.face_quan_num}", G=args.face_quan_num,
+                              c=args.zquant_dim, V3=args.in_dim, n_books=max(1, args.n_embed // 256))
+        presets.PRESETS[self.preset.name] = self.preset
+        for k, v in synth.make_vq_weights(self.preset.name).items():
+            self._register(k, v)
+        self._register("decoder.decoder_pos_embedding.pe",
+                       schedule.positional_table(presets.VQ_HIDDEN, "sinus", 1, 5000).unsqueeze(1), buffer=True)
+        self._dtype = compute_dtype(dtype)
+        self._plan = None
+        self._plan_stale = True
+
+    def plan(self, device):
+        if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
+            self._plan = VQPlan(self.preset, self.state_dict(), self._dtype, device)
+            self._plan_stale = False
+        return self._plan
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        # the training-only encoder.* tensors of a reference checkpoint are not part of the sampling path
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("encoder.")}
+        return super().load_state_dict(sd, strict=strict, **kw)
+
+    def quant(self, x, one_hot=None):
+        """-> (z_q [B, c, L*G], emb_loss, (perplexity, min_encodings, indices)); the training-only
+        outputs (loss, perplexity, one-hot encodings) are not produced on the sampling path (None)."""
+        if not x.is_cuda:
+            raise FdmError("VQAutoEncoder.quant runs on the HIP path only")
+        emo = None if one_hot is None else one_hot.reshape(-1, one_hot.shape[-1])
+        zq, idx = self.plan(x.device).quant(x, emo)
+        return zq, None, (None, None, idx)
+
+    def decode(self, quant):
+        if not quant.is_cuda:
+            raise FdmError("VQAutoEncoder.decode runs on the HIP path only")
+        return self.plan(quant.device).decode(quant)

@@ -1,0 +1,136 @@
+"""End-to-end clip pipeline: wav -> processor normalisation -> HuBERT -> T-step sampling -> quant ->
+decode (+ template) -> [B, L, V3] vertices, as wired by the reference's coherent callers
+(samples/sample_diffusion_vocaset.py:59-88, samples/sample_diffusion_mead.py:67-86) and intended by
+demo/demo_*.py:77-106 (flags + I/O layout kept; the demos' undefined names are re-wired per samples/)."""
+import os
+
+import numpy as np
+import torch
+
+from . import presets
+from .modules import (FDM, ClassifierFreeSampleModel, FDMBiwi, FDMMead, GaussianDiffusion, VQAutoEncoder)
+
+EMOTIONS = ["angry", "contempt", "disgusted", "fear", "happy", "sad", "surprised"]     # demo/demo_3d_mead.py:118
+
+
+def load_wav(path, sr=16000):
+    """16 kHz mono float32 (librosa.load(sr=16000) of the demos; scipy-based, no librosa here)."""
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+    rate, x = wavfile.read(path)
+    if x.dtype.kind == "i":
+        x = x.astype(np.float32) / float(np.iinfo(x.dtype).max + 1)
+    elif x.dtype.kind == "u":
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    x = x.astype(np.float32)
+    if x.ndim > 1:
+        x = x.mean(axis=1)
+    if rate != sr:
+        g = np.gcd(int(rate), sr)
+        x = resample_poly(x, sr // g, int(rate) // g).astype(np.float32)
+    return x
+
+
+def processor_normalize(x, pad_seconds=1.0, sr=16000):
+    """Wav2Vec2Processor default: zero mean / unit variance ((x - mu)/sqrt(var + 1e-7)), then the demo's
+    1 s of trailing zeros (demo/demo_vocaset.py:84-90)."""
+    x = np.asarray(x, dtype=np.float32)
+    x = (x - x.mean()) / np.sqrt(x.var() + 1e-7)
+    if pad_seconds:
+        x = np.concatenate([x, np.zeros(int(pad_seconds * sr), dtype=np.float32)])
+    return x.astype(np.float32)
+
+
+def build_models(preset="vocaset", feature_dim=None, device="cuda:0", stage1=None, stage2=None, dtype=None, cfg_level=None):
+    """(diffusion, autoencoder) with reference-compatible state dicts; checkpoints are loaded when the
+    files exist ('model' / 'state_dict' keys as samples/sample_diffusion_vocaset.py:26,91-97), otherwise the
+    seeded random init is kept (there are no checkpoints in this environment)."""
+    from dropin_config import vq_args_for
+    p = presets.get(preset)
+    cls = {"vocaset": FDM, "mead": FDMMead, "biwi": FDMBiwi}[p.name]
+    kw = dict(feature_dim=feature_dim or p.d, n_head=(feature_dim or p.d) // 128, dtype=dtype)
+    model = cls(**kw)
+    ae = VQAutoEncoder(vq_args_for(p.name), dtype=dtype)
+    denoise = ClassifierFreeSampleModel(model, cfg_level) if cfg_level else model
+    diffusion = GaussianDiffusion(denoise, timesteps=1000, loss_type="l2")
+    if stage2 and os.path.exists(stage2):
+        diffusion.load_state_dict(torch.load(stage2, map_location="cpu")["model"], strict=False)
+    else:
+        # untrained latent_decoder is zero-initialised in the reference (outputs would be identically 0):
+        # give the synthetic model a non-trivial head so the pipeline is exercised end to end
+        g = torch.Generator().manual_seed(7)
+        model.latent_decoder.weight.data.copy_(torch.randn(model.latent_decoder.weight.shape, generator=g) * 0.02)
+    if stage1 and os.path.exists(stage1):
+        ck = torch.load(stage1, map_location="cpu")
+        ae.load_state_dict(ck.get("state_dict", ck.get("model", ck)), strict=False)
+    return diffusion, ae
+
+
+@torch.no_grad()
+def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emotion_one_hot=None, steps=None,
+            ddim_steps=None, seed=0, device="cuda:0"):
+    """audio [B, n] (processor-normalised) -> vertices [B, L, V3].  DDPM full chain by default, DDIM if ddim_steps."""
+    model = diffusion.denoise_fn.model if isinstance(diffusion.denoise_fn, ClassifierFreeSampleModel) else diffusion.denoise_fn
+    p = model.preset
+    audio = torch.as_tensor(audio, dtype=torch.float32, device=device)
+    if audio.dim() == 1:
+        audio = audio.unsqueeze(0)
+    B = audio.shape[0]
+    if id_one_hot is None:
+        id_one_hot = torch.eye(p.n_style)[:1].expand(B, -1)
+    id_one_hot = id_one_hot.to(device)
+    hub = model.audio_features(audio)
+    L = min(hub.shape[1] // p.pair, p.max_len)        # samples/sample_diffusion_vocaset.py:76 (no interpolation, a17b)
+    shape = (B, L * p.G, p.c)
+    if p.n_emo:
+        if emotion_one_hot is None:
+            emotion_one_hot = torch.eye(p.n_emo)[4:5].expand(B, -1)
+        emotion_one_hot = emotion_one_hot.to(device)
+        latent = diffusion.sample(audio, shape, emotion_one_hot, id_one_hot, seed=seed)
+        quanted, _, _ = autoencoder.quant(latent, emotion_one_hot)
+    else:
+        if ddim_steps:
+            g = torch.Generator(device="cpu").manual_seed(seed)
+            latent = diffusion.ddim_sample(audio, shape, id_one_hot, ddim_steps, x_T=torch.randn(shape, generator=g))
+        else:
+            latent = diffusion.sample(audio, shape, id_one_hot, seed=seed)
+        quanted, _, _ = autoencoder.quant(latent)
+    out = autoencoder.decode(quanted)
+    if template is not None:
+        out = out + torch.as_tensor(template, dtype=torch.float32, device=device).reshape(-1, 1, out.shape[-1])
+    return out, latent
+
+
+def demo_main(preset, argv=None):
+    """CLI of demo/demo_{vocaset,biwi,3d_mead}.py:109-121: same flags, output = np.save(<audio_path>/<stem>.npy, [1, L, V3])."""
+    import argparse
+    p = presets.get(preset)
+    ap = argparse.ArgumentParser(description="Expressive 3D Facial Animation Generation Based on Local-to-global Latent Diffusion")
+    ap.add_argument("--audio_file", type=str, help="the audio file path for prediction")
+    if p.n_emo:
+        ap.add_argument("--emotion", type=str, default="happy", choices=EMOTIONS)
+    ap.add_argument("--vertice_dim", type=int, default=p.V3)
+    ap.add_argument("--feature_dim", type=int, default=p.d)
+    ap.add_argument("--device", type=str, default="cuda:0")
+    ap.add_argument("--template_file", type=str, default="templates.pkl")
+    ap.add_argument("--stage1_model_path", type=str, default=f"{p.name}/{p.name}_stage1.mpt")
+    ap.add_argument("--stage2_model_path", type=str, default=f"{p.name}/{p.name}_stage2.mpt")
+    ap.add_argument("--audio_path", type=str, default=f"{p.name}/result")
+    ap.add_argument("--ddim_steps", type=int, default=0, help="build-added: DDIM steps (0 = full DDPM chain)")
+    ap.add_argument("--seed", type=int, default=0)
+    a = ap.parse_args(argv)
+    diffusion, ae = build_models(p.name, a.feature_dim, a.device, a.stage1_model_path, a.stage2_model_path,
+                                 cfg_level=None)
+    wav = processor_normalize(load_wav(a.audio_file))
+    template = None
+    if os.path.exists(a.template_file) and a.template_file.endswith(".npy"):
+        template = np.load(a.template_file).reshape(1, -1)
+    emo = None
+    if p.n_emo:
+        emo = torch.eye(p.n_emo)[EMOTIONS.index(a.emotion)].unsqueeze(0)
+    out, _ = animate(diffusion, ae, wav, template, None, emo, ddim_steps=a.ddim_steps, seed=a.seed, device=a.device)
+    os.makedirs(a.audio_path, exist_ok=True)
+    dst = os.path.join(a.audio_path, os.path.basename(a.audio_file)[:-4])
+    np.save(dst, out.detach().cpu().numpy())
+    print(f"saved {dst}.npy {tuple(out.shape)}")
+    return dst + ".npy"

@@ -384,6 +384,30 @@ def g9_audio():
          adain_out=ar.numpy())
 
 
+def g10_state_keys():
+    """Names + shapes of the reference state dicts (the checkpoint-compatibility surface)."""
+    import json
+    import models.hubert as rh
+    from models.fdm_vocaset import FDM as F1
+    from models.fdm_vqvae_mead import FDM as F2
+    from video_diffusion_pytorch.diffusion_BIWI_encoder_decoder import GaussianDiffusion
+    from models.utils.config import vocaset_vq_vae_args, vq_vae_args, biwi_vq_vae_args
+    from models.vq_vae_vocaset import VQAutoEncoder as V1
+    from models.vq_vae_emotion import VQAutoEncoder as V2
+    from models.vq_vae import VQAutoEncoder as V3
+    refshim.install(hubert_layers=24)
+    out = {}
+    sd = lambda m: {k: list(v.shape) for k, v in m.state_dict().items()}
+    out["diffusion_vocaset"] = sd(GaussianDiffusion(F1(feature_dim=1024), timesteps=1000, loss_type="l2"))
+    out["fdm_mead"] = sd(F2(feature_dim=512))
+    out["vq_vocaset"] = sd(V1(vocaset_vq_vae_args()))
+    out["vq_mead"] = sd(V2(vq_vae_args()))
+    out["vq_biwi"] = sd(V3(biwi_vq_vae_args()))
+    path = os.path.join(HERE, "state_keys.json")
+    json.dump(out, open(path, "w"))
+    print(f"  wrote state_keys.json ({os.path.getsize(path) / 1024:.0f} KiB)", {k: len(v) for k, v in out.items()})
+
+
 ALL = {
     "schedule": g1_schedule, "masks": g2_masks,
     "fdm_step_vocaset": lambda: g3_fdm_step("vocaset"),
@@ -393,7 +417,7 @@ ALL = {
     "chains_vocaset": lambda: g4_chains("vocaset"),
     "chains_mead": lambda: g4_chains("mead"),
     "chains_vocaset_tiny": lambda: g4_chains("vocaset_tiny"),
-    "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio,
+    "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio, "state_keys": g10_state_keys,
 }
 
 if __name__ == "__main__":
