@@ -64,20 +64,35 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
   const int kend = p.causal ? min(q0 + 16, L) : L;     // keys [0, kend) can be visible to this tile
   const int ntiles = (kend + KT - 1) / KT;
 
-  for (int kt = 0; kt < ntiles; ++kt) {
+  // K fragments of a tile are fetched one tile ahead and the V^T fragments at the top of the tile, so the
+  // L2 round trips overlap the MFMAs and the softmax of the current tile instead of serialising with them.
+  auto load_k = [&](int kt, u32x4 (&kf)[NSUB][NKS]) {
     const int kbase = kt * KT;
-    f32x4 sc[NSUB];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
       // key fed by A-port row r16 of sub-tile s
       const int krow = (NSUB == 2) ? (kbase + 8 * (r16 >> 2) + 4 * s + (r16 & 3)) : (kbase + r16);
       const T* kp = K + (size_t)min(krow, L - 1) * p.ldk;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) kf[s][ks] = *(const u32x4*)(kp + (ks * 4 + g) * EPC);
+    }
+  };
+  u32x4 kcur[NSUB][NKS], knext[NSUB][NKS];
+  load_k(0, kcur);
+  const float inv_period = 1.f / (float)p.period;
+
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int kbase = kt * KT;
+    u32x4 vf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) vf[c] = *(const u32x4*)(Vt + (size_t)(c * 16 + r16) * p.Lpad + kbase + g * EPC);
+    if (kt + 1 < ntiles) load_k(kt + 1, knext);
+    f32x4 sc[NSUB];
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s) {
       f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        u32x4 kf = *(const u32x4*)(kp + (ks * 4 + g) * EPC);
-        Mma<T>::run(a, kf, qf[ks]);
-      }
+      for (int ks = 0; ks < NKS; ++ks) Mma<T>::run(a, kcur[s][ks], qf[ks]);
       sc[s] = a;
     }
     // scores -> scaled, biased, masked; this lane holds keys kbase + (NSUB==2 ? 8g+4s+r : 4g+r)
@@ -88,7 +103,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
       for (int r = 0; r < 4; ++r) {
         const int kj = kbase + ((NSUB == 2) ? (8 * g + 4 * s + r) : (4 * g + r));
         float v = sc[s][r] * p.scale;
-        if (p.slopes) v -= slope * (float)((qi - kj) / p.period);
+        // floor((qi - kj) / period) without an integer divide: (n + 0.5) / period never rounds across an integer
+        if (p.slopes) v -= slope * floorf(((float)(qi - kj) + 0.5f) * inv_period);
         const bool masked = (kj >= L) || (p.causal && kj > qi);
         v = masked ? -INFINITY : v;
         sc[s][r] = v;
@@ -123,10 +139,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
       pf = __builtin_bit_cast(u32x4, sc[0]);
     }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      u32x4 vf = *(const u32x4*)(Vt + (size_t)(c * 16 + r16) * p.Lpad + kbase + g * EPC);
-      Mma<T>::run(o[c], vf, pf);
-    }
+    for (int c = 0; c < NC; ++c) Mma<T>::run(o[c], vf[c], pf);
+#pragma unroll
+    for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) kcur[s][ks] = knext[s][ks];
   }
 
   float l_tot = l_part;

@@ -26,11 +26,12 @@ __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
   }
   f32x4 v[NV];
   float s = 0.f;
+  const bool two = p.gamma2 != nullptr;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int col = (i * 64 + lane) * 4;
     f32x4 a = *(const f32x4*)(xr + col);
-    if (am || at) {
+    if (!two && (am || at)) {
       f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
       if (am) e = *(const f32x4*)(am + col);
       if (at) e += *(const f32x4*)(at + col);
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
     v[i] = a;
     s += (a[0] + a[1]) + (a[2] + a[3]);
   }
-  const float mean = wave_sum(s) * (1.f / d);
+  float mean = wave_sum(s) * (1.f / d);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -47,13 +48,41 @@ __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
     v[i] = c;
     q += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
   }
+  if (two) {
+    // stage 1 -> h = LN1(x); stage 2 input = h + add_mat + add_tab[idx]
+    const float rstd1 = 1.f / sqrtf(wave_sum(q) * (1.f / d) + p.eps);
+    s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int col = (i * 64 + lane) * 4;
+      f32x4 a = v[i] * rstd1 * *(const f32x4*)(p.gamma + col) + *(const f32x4*)(p.beta + col);
+      if (am || at) {
+        f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (am) e = *(const f32x4*)(am + col);
+        if (at) e += *(const f32x4*)(at + col);
+        a += e;
+      }
+      v[i] = a;
+      s += (a[0] + a[1]) + (a[2] + a[3]);
+    }
+    mean = wave_sum(s) * (1.f / d);
+    q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 c = v[i] - mean;
+      v[i] = c;
+      q += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+    }
+  }
+  const float* gam = two ? p.gamma2 : p.gamma;
+  const float* bet = two ? p.beta2 : p.beta;
   const float var = wave_sum(q) * (1.f / d);
   const float rstd = 1.f / sqrtf(var + p.eps);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int col = (i * 64 + lane) * 4;
-    f32x4 gm = *(const f32x4*)(p.gamma + col);
-    f32x4 bt = *(const f32x4*)(p.beta + col);
+    f32x4 gm = *(const f32x4*)(gam + col);
+    f32x4 bt = *(const f32x4*)(bet + col);
     f32x4 y = v[i] * rstd * gm + bt;
     if (p.act != ACT_NONE) {
 #pragma unroll
@@ -119,7 +148,16 @@ __device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigne
 // reference's unfused torch expression order.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sched_kernel(const fdm_sched_args p) {
-  const int k = p.step ? *p.step : 0;
+  const int k = p.step ? *(volatile const int*)p.step : 0;
+  if (p.arrive && p.advance && threadIdx.x == 0) {
+    // every block reads *step first, then takes a ticket; the block holding the last ticket knows all
+    // reads are done and advances the counter (and re-arms the ticket word) -- no separate launch
+    const unsigned tk = atomicAdd(p.arrive, 1u);
+    if (tk == gridDim.x - 1) {
+      *p.arrive = 0u;
+      *p.step = k + 1;
+    }
+  }
   const int t = p.tseq ? p.tseq[k] : k;
   const long long nq = p.n / 4;
   float c1 = 0.f, c2 = 0.f, sg = 0.f, sra = 0.f, srm1 = 1.f, san = 0.f, cn = 0.f;
@@ -143,7 +181,7 @@ __global__ __launch_bounds__(256) void sched_kernel(const fdm_sched_args p) {
         if (t > 0) {
           f32x4 z;
           if (p.noise) {
-            z = *(const f32x4*)(p.noise + (size_t)k * p.n + 4 * i);
+            z = *(const f32x4*)(p.noise + (size_t)k * (p.noise_stride > 0 ? p.noise_stride : p.n) + 4 * i);
           } else {
             const long long e = 4 * i;
             const int clip = (int)(e / p.n_per_clip);
@@ -162,6 +200,15 @@ __global__ __launch_bounds__(256) void sched_kernel(const fdm_sched_args p) {
       }
     }
     *(f32x4*)(p.x_out + 4 * i) = o;
+    if (p.x_out_t) {
+      if (p.out_dtype == FDM_BF16) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 ob = {(bf16)o[0], (bf16)o[1], (bf16)o[2], (bf16)o[3]};
+        *(bf16x4*)((bf16*)p.x_out_t + 4 * i) = ob;
+      } else {
+        *(f32x4*)((float*)p.x_out_t + 4 * i) = o;
+      }
+    }
   }
 }
 
@@ -175,7 +222,7 @@ static hipError_t sched_launch(const fdm_sched_args& a, hipStream_t s) {
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(sched_kernel, dim3(blocks), dim3(256), 0, s, a);
-  if (a.advance && a.step) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, a.step);
+  if (a.advance && a.step && !a.arrive) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, a.step);
   return hipGetLastError();
 }
 

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fdm_hip.h"
@@ -38,8 +39,13 @@ using Op = std::function<hipError_t(hipStream_t)>;
 
 struct fdm_prog {
   std::vector<Op> ops;
-  hipGraph_t graph = nullptr;
-  hipGraphExec_t exec = nullptr;
+  std::vector<int> lane;        // lane (independent chain) of each op; lanes run as parallel graph branches
+  int cur_lane = 0, n_lanes = 1;
+  std::vector<hipStream_t> lane_streams;     // one per lane when n_lanes > 1
+  std::vector<hipEvent_t> lane_events;
+  hipEvent_t fork_event = nullptr;
+  std::vector<hipGraph_t> graphs;            // one captured graph per lane
+  std::vector<hipGraphExec_t> execs;
 };
 
 namespace {
@@ -50,6 +56,7 @@ thread_local fdm_prog* g_rec = nullptr;
 int submit(Op op, void* stream, const char* what) {
   if (g_rec) {
     g_rec->ops.push_back(std::move(op));
+    g_rec->lane.push_back(g_rec->cur_lane);
     return FDM_OK;
   }
   hipError_t e = op((hipStream_t)stream);
@@ -237,8 +244,11 @@ int fdm_prog_create(fdm_prog** out) {
 int fdm_prog_destroy(fdm_prog* p) {
   if (!p) return FDM_OK;
   if (g_rec == p) g_rec = nullptr;
-  if (p->exec) (void)hipGraphExecDestroy(p->exec);
-  if (p->graph) (void)hipGraphDestroy(p->graph);
+  for (auto x : p->execs) (void)hipGraphExecDestroy(x);
+  for (auto g : p->graphs) (void)hipGraphDestroy(g);
+  for (auto e : p->lane_events) (void)hipEventDestroy(e);
+  if (p->fork_event) (void)hipEventDestroy(p->fork_event);
+  for (auto st : p->lane_streams) (void)hipStreamDestroy(st);
   delete p;
   return FDM_OK;
 }
@@ -246,7 +256,7 @@ int fdm_prog_destroy(fdm_prog* p) {
 int fdm_prog_begin(fdm_prog* p) {
   if (!p) return fail(FDM_ERR_ARG, "prog_begin: null program");
   if (g_rec) return fail(FDM_ERR_STATE, "prog_begin: another program is recording on this thread");
-  if (p->exec) return fail(FDM_ERR_STATE, "prog_begin: program already instantiated");
+  if (!p->execs.empty()) return fail(FDM_ERR_STATE, "prog_begin: program already instantiated");
   g_rec = p;
   return FDM_OK;
 }
@@ -258,6 +268,14 @@ int fdm_prog_end(fdm_prog* p) {
 }
 
 int fdm_prog_num_ops(fdm_prog* p) { return p ? (int)p->ops.size() : 0; }
+
+int fdm_prog_set_lane(fdm_prog* p, int lane) {
+  if (!p || g_rec != p) return fail(FDM_ERR_STATE, "prog_set_lane: program is not recording");
+  if (lane < 0 || lane >= 64) return fail(FDM_ERR_ARG, "prog_set_lane: lane %d outside [0, 64)", lane);
+  p->cur_lane = lane;
+  if (lane + 1 > p->n_lanes) p->n_lanes = lane + 1;
+  return FDM_OK;
+}
 
 int fdm_prog_run(fdm_prog* p, void* stream) {
   if (!p) return fail(FDM_ERR_ARG, "prog_run: null program");
@@ -272,29 +290,79 @@ int fdm_prog_run(fdm_prog* p, void* stream) {
 int fdm_prog_instantiate(fdm_prog* p, void* stream) {
   if (!p) return fail(FDM_ERR_ARG, "prog_instantiate: null program");
   if (g_rec) return fail(FDM_ERR_STATE, "prog_instantiate: a program is still recording");
-  if (p->exec) return FDM_OK;
+  if (!p->execs.empty()) return FDM_OK;
   if (p->ops.empty()) return fail(FDM_ERR_STATE, "prog_instantiate: empty program");
-  hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-  if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
-  hipError_t opErr = hipSuccess;
-  for (auto& op : p->ops) {
-    opErr = op(s);
-    if (opErr != hipSuccess) break;
+  hipError_t e;
+  // One graph per lane.  Lanes are dependency-free chains; each lane's graph is replayed on its own
+  // stream so that the chains overlap on the device (parallel branches inside ONE hipGraph are executed
+  // back to back by the ROCm 7.2 graph executor -- measured -- so the fork is made across streams instead).
+  if (p->n_lanes > 1 && p->lane_streams.empty()) {
+    if ((e = hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    for (int i = 0; i < p->n_lanes; ++i) {
+      hipStream_t st; hipEvent_t ev;
+      if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+      p->lane_streams.push_back(st);
+      p->lane_events.push_back(ev);
+    }
   }
-  e = hipStreamEndCapture(s, &p->graph);
-  if (opErr != hipSuccess) return hip_fail(opErr, "prog_instantiate (launch during capture)");
-  if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
-  e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
-  if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
+  for (int ln = 0; ln < p->n_lanes; ++ln) {
+    hipStream_t s = p->n_lanes > 1 ? p->lane_streams[ln] : (hipStream_t)stream;
+    e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
+    hipError_t opErr = hipSuccess;
+    int n_ops = 0;
+    for (size_t i = 0; opErr == hipSuccess && i < p->ops.size(); ++i)
+      if (p->lane[i] == ln) { opErr = p->ops[i](s); ++n_ops; }
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(s, &g);
+    if (opErr != hipSuccess) return hip_fail(opErr, "prog_instantiate (launch during capture)");
+    if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+    if (n_ops == 0) return fail(FDM_ERR_STATE, "prog_instantiate: lane %d has no ops", ln);
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
+    p->graphs.push_back(g);
+    p->execs.push_back(x);
+  }
   return FDM_OK;
 }
 
 int fdm_prog_replay(fdm_prog* p, int n, void* stream) {
-  if (!p || !p->exec) return fail(FDM_ERR_STATE, "prog_replay: program not instantiated");
-  for (int i = 0; i < n; ++i) {
-    hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
-    if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
+  if (!p || p->execs.empty()) return fail(FDM_ERR_STATE, "prog_replay: program not instantiated");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (p->n_lanes == 1) {
+    for (int i = 0; i < n; ++i)
+      if ((e = hipGraphLaunch(p->execs[0], s)) != hipSuccess) return hip_fail(e, "hipGraphLaunch");
+    return FDM_OK;
+  }
+  // fork: every lane stream waits for the work already queued on the caller's stream
+  if ((e = hipEventRecord(p->fork_event, s)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+  for (auto st : p->lane_streams)
+    if ((e = hipStreamWaitEvent(st, p->fork_event, 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+  // lanes free-run for all n replays (no per-step join: chains share nothing, not even the step counter).
+  // Graph launch costs the host a few microseconds per kernel node, so each lane is fed by its own
+  // host thread; otherwise one thread feeding L lanes would be the bottleneck.
+  {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::vector<hipError_t> errs(p->n_lanes, hipSuccess);
+    std::vector<std::thread> th;
+    for (int ln = 0; ln < p->n_lanes; ++ln)
+      th.emplace_back([p, ln, n, dev, &errs] {
+        hipError_t er = hipSetDevice(dev);
+        for (int i = 0; er == hipSuccess && i < n; ++i) er = hipGraphLaunch(p->execs[ln], p->lane_streams[ln]);
+        errs[ln] = er;
+      });
+    for (auto& t : th) t.join();
+    for (auto er : errs)
+      if (er != hipSuccess) return hip_fail(er, "hipGraphLaunch (lane thread)");
+  }
+  // join
+  for (int ln = 0; ln < p->n_lanes; ++ln) {
+    if ((e = hipEventRecord(p->lane_events[ln], p->lane_streams[ln])) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    if ((e = hipStreamWaitEvent(s, p->lane_events[ln], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
   }
   return FDM_OK;
 }

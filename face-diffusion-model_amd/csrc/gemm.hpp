@@ -14,10 +14,96 @@
 //    bias/residual and writes outputs with 16-byte (fp32) / 8-byte (bf16) vector accesses.
 //  * Epilogue is fused: bias, activation, residual add, dual-dtype stores, transposed "V^T" scatter.
 #pragma once
+#include <cstdlib>
+
 #include "common.hpp"
 #include "../../include/fdm_hip.h"
 
 namespace fdm {
+
+template <typename T, int BM, int BN, int WM = 2, int WN = 2>
+__device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0, int z,
+                                              int wm, int wn, int g, int r16) {
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  const int M = p.M, N = p.N;
+  // ---- fused epilogue: lane owns C[m = .. + r16][n = .. + 4g + (0..3)] ----
+  const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
+  const size_t ocol = (size_t)z * p.out_batch_stride;
+  const bool vec_f32 = p.out_f32 && (p.ldo_f32 % 4 == 0) && (((uintptr_t)(p.out_f32 + ocol)) % 16 == 0);
+  const bool vec_t = p.out_t && (p.ldo_t % 4 == 0) && (((uintptr_t)((T*)p.out_t + ocol)) % (4 * sizeof(T)) == 0);
+  const bool vec_r = p.resid && (p.ldr % 4 == 0) && (((uintptr_t)(p.resid + ocol)) % 16 == 0);
+  const int vt_H = p.out_vt ? (N - p.vt_col0) / p.vt_hd : 0;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int m = m0 + wm * (BM / WM) + mi * 16 + r16;
+    if (m >= M) continue;
+    const size_t rrow = p.resid_row_mod > 0 ? (size_t)(m % p.resid_row_mod) : (size_t)m;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * g;
+      if (n >= N) continue;
+      f32x4 v = acc[mi][ni];
+      const bool full = (n + 3 < N);
+      if (bias) {
+        if (full) {
+          f32x4 b = *(const f32x4*)(bias + n);
+          v += b;
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (n + j < N) v[j] += bias[n + j];
+        }
+      }
+      if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
+      }
+      if (p.resid) {
+        const float* rp = p.resid + ocol + rrow * p.ldr + n;
+        if (full && vec_r) {
+          v += *(const f32x4*)rp;
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (n + j < N) v[j] += rp[j];
+        }
+      }
+      if (p.out_vt && n >= p.vt_col0) {
+        // scatter transposed: Vt[((b*H + h)*hd + e)*Lpad + l]
+        const int b = m / p.vt_L, l = m - b * p.vt_L;
+        for (int j = 0; j < 4; ++j) {
+          if (n + j >= N) break;
+          const int cc = n + j - p.vt_col0;
+          const int h = cc / p.vt_hd, e = cc - h * p.vt_hd;
+          ((T*)p.out_vt)[((size_t)(b * vt_H + h) * p.vt_hd + e) * p.vt_Lpad + l] = from_f32<T>(v[j]);
+        }
+        continue;
+      }
+      if (p.out_f32) {
+        float* op = p.out_f32 + ocol + (size_t)m * p.ldo_f32 + n;
+        if (full && vec_f32) {
+          *(f32x4*)op = v;
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (n + j < N) op[j] = v[j];
+        }
+      }
+      if (p.out_t) {
+        T* op = (T*)p.out_t + ocol + (size_t)m * p.ldo_t + n;
+        if (full && vec_t) {
+          if constexpr (sizeof(T) == 4) {
+            *(f32x4*)op = v;
+          } else {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)op = o;
+          }
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (n + j < N) op[j] = from_f32<T>(v[j]);
+        }
+      }
+    }
+  }
+}
 
 template <typename T, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(const fdm_gemm_args p) {
@@ -111,84 +197,123 @@ __global__ __launch_bounds__(256) void gemm_kernel(const fdm_gemm_args p) {
     }
     __syncthreads();
   }
+  gemm_epilogue<T, BM, BN>(p, acc, m0, n0, z, wm, wn, g, r16);
+}
 
-  // ---- fused epilogue: lane owns C[m = .. + r16][n = .. + 4g + (0..3)] ----
-  const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
-  const size_t ocol = (size_t)z * p.out_batch_stride;
-  const bool vec_f32 = p.out_f32 && (p.ldo_f32 % 4 == 0) && (((uintptr_t)(p.out_f32 + ocol)) % 16 == 0);
-  const bool vec_t = p.out_t && (p.ldo_t % 4 == 0) && (((uintptr_t)((T*)p.out_t + ocol)) % (4 * sizeof(T)) == 0);
-  const bool vec_r = p.resid && (p.ldr % 4 == 0) && (((uintptr_t)(p.resid + ocol)) % 16 == 0);
-  const int vt_H = p.out_vt ? (N - p.vt_col0) / p.vt_hd : 0;
+// ---------------------------------------------------------------------------------------------------
+// v2 main loop: HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into an NST-stage
+// ring, tiles prefetched NST-1 deep, counted s_waitcnt vmcnt (never 0 in steady state), one raw
+// s_barrier per k-tile.  The LDS image of a stage is lane-linear (a wave instruction writes 1 KiB =
+// 8 rows x 128 B), so the bank-conflict swizzle is applied to the SOURCE chunk (slot ^ (row & 7)) and
+// undone by the same XOR on the ds_read side.
+// The step's GEMMs have M = B*L of a few hundred rows: a block owns one tile for the whole K loop, so
+// what bounds it is the latency chain of its own k-tiles, not bandwidth -- hence the deep ring.
+// ---------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
+  // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
+  constexpr int NW = WM * WN;
+  constexpr int ROWB = KCH * 16;                 // bytes per LDS row
+  constexpr int RPI = 1024 / ROWB;               // rows written by one wave-wide LDS-DMA instruction
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  constexpr int A_IPW = BM / RPI / NW, W_IPW = BN / RPI / NW;     // glds instructions per wave per k-tile
+  static_assert(A_IPW >= 1 && W_IPW >= 1 && MI >= 1 && NI >= 1, "tile too small for the wave grid");
+  constexpr int P = A_IPW + W_IPW;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int M = p.M, N = p.N;
+  const T* A = (const T*)p.A + (size_t)z * p.a_batch_stride;
+  const T* W = (const T*)p.W + (size_t)z * p.w_batch_stride;
+
+  // per-lane source pointers (k-tile 0); LDS row groups are wave-uniform.  The LDS image is
+  // lane-linear, so the swizzle sits on the source: lane (row, slot) fetches chunk slot ^ (row % KCH).
+  const int lrow = lane / KCH, slot = lane % KCH;
+  const char* a_src[A_IPW];
+  const char* w_src[W_IPW];
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int m = m0 + wm * (BM / 2) + mi * 16 + r16;
-    if (m >= M) continue;
-    const size_t rrow = p.resid_row_mod > 0 ? (size_t)(m % p.resid_row_mod) : (size_t)m;
+  for (int i = 0; i < A_IPW; ++i) {
+    const int row = RPI * (wave * A_IPW + i) + lrow;
+    a_src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * p.lda) + ((slot ^ (row % KCH)) << 4);
+  }
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      const int n = n0 + wn * (BN / 2) + ni * 16 + 4 * g;
-      if (n >= N) continue;
-      f32x4 v = acc[mi][ni];
-      const bool full = (n + 3 < N);
-      if (bias) {
-        if (full) {
-          f32x4 b = *(const f32x4*)(bias + n);
-          v += b;
-        } else {
-          for (int j = 0; j < 4; ++j)
-            if (n + j < N) v[j] += bias[n + j];
-        }
-      }
-      if (p.act != ACT_NONE) {
+  for (int i = 0; i < W_IPW; ++i) {
+    const int row = RPI * (wave * W_IPW + i) + lrow;
+    w_src[i] = (const char*)(W + (size_t)min(n0 + row, N - 1) * p.ldw) + ((slot ^ (row % KCH)) << 4);
+  }
+  auto issue = [&](int kt) {
+    char* sb = smem + (kt % NST) * STAGE;
+    const size_t off = (size_t)kt * ROWB;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
+    for (int i = 0; i < A_IPW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off), (lptr_t)(sb + (wave * A_IPW + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < W_IPW; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + off), (lptr_t)(sb + BM * ROWB + (wave * W_IPW + i) * 1024), 16, 0, 0);
+  };
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int EPC = 16 / (int)sizeof(T);
+  const int nk = p.K / (KCH * EPC);
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nk) issue(t);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    // tile kt has landed once at most the (NST-2) younger tiles of this wave are still in flight
+    if (kt + NST - 2 < nk) wait_vmcnt<(NST - 2) * P>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();           // everyone's part of tile kt landed; stage (kt-1)%NST is free
+    if (kt + NST - 1 < nk) issue(kt + NST - 1);
+    const char* base = smem + (kt % NST) * STAGE;
+#pragma unroll
+    for (int s = 0; s < KCH / 4; ++s) {
+      u32x4 af[MI], wf[NI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int row = wm * (BM / WM) + mi * 16 + r16;
+        af[mi] = *(const u32x4*)(base + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
       }
-      if (p.resid) {
-        const float* rp = p.resid + ocol + rrow * p.ldr + n;
-        if (full && vec_r) {
-          v += *(const f32x4*)rp;
-        } else {
-          for (int j = 0; j < 4; ++j)
-            if (n + j < N) v[j] += rp[j];
-        }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        const int row = wn * (BN / WN) + ni * 16 + r16;
+        wf[ni] = *(const u32x4*)(base + BM * ROWB + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
       }
-      if (p.out_vt && n >= p.vt_col0) {
-        // scatter transposed: Vt[((b*H + h)*hd + e)*Lpad + l]
-        const int b = m / p.vt_L, l = m - b * p.vt_L;
-        for (int j = 0; j < 4; ++j) {
-          if (n + j >= N) break;
-          const int cc = n + j - p.vt_col0;
-          const int h = cc / p.vt_hd, e = cc - h * p.vt_hd;
-          ((T*)p.out_vt)[((size_t)(b * vt_H + h) * p.vt_hd + e) * p.vt_Lpad + l] = from_f32<T>(v[j]);
-        }
-        continue;
-      }
-      if (p.out_f32) {
-        float* op = p.out_f32 + ocol + (size_t)m * p.ldo_f32 + n;
-        if (full && vec_f32) {
-          *(f32x4*)op = v;
-        } else {
-          for (int j = 0; j < 4; ++j)
-            if (n + j < N) op[j] = v[j];
-        }
-      }
-      if (p.out_t) {
-        T* op = (T*)p.out_t + ocol + (size_t)m * p.ldo_t + n;
-        if (full && vec_t) {
-          if constexpr (sizeof(T) == 4) {
-            *(f32x4*)op = v;
-          } else {
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *(bf16x4*)op = o;
-          }
-        } else {
-          for (int j = 0; j < 4; ++j)
-            if (n + j < N) op[j] = from_f32<T>(v[j]);
-        }
-      }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], af[mi]);
     }
   }
+  gemm_epilogue<T, BM, BN, WM, WN>(p, acc, m0, n0, z, wm, wn, g, r16);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
+static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
+  constexpr int lds = NST * (BM + BN) * KCH * 16;
+  static bool once = [] {
+    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+  }();
+  (void)once;
+  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH>), grid, dim3(64 * WM * WN), lds, s, a);
+  return hipGetLastError();
 }
 
 template <typename T, int BM, int BN>
@@ -199,17 +324,38 @@ static hipError_t gemm_launch_t(const fdm_gemm_args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-// Tile choice: the path's GEMMs have M = B*L of a few hundred to a few thousand rows, so a
-// 128x128 tiling often leaves most of the 256 CUs idle; fall back to 64x64 until the 128x128
-// grid covers the chip at least ~1.5 times.
-static hipError_t gemm_launch(const fdm_gemm_args& a, hipStream_t s) {
+// Tile choice.  FDM_GEMM_VARIANT (env, read once) selects a kernel family for A/B measurements:
+//   0 = v1 register-staged double buffer (64x64 / 128x128), 1 = v2 LDS-DMA ring (default).
+static int gemm_variant() {
+  static int v = [] { const char* e = getenv("FDM_GEMM_VARIANT"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+template <typename T>
+static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   const long long batch = a.batch > 0 ? a.batch : 1;
-  const long long big = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
-  const bool use_big = big >= 384;
-  if (a.dtype == FDM_BF16) {
-    return use_big ? gemm_launch_t<bf16, 128, 128>(a, s) : gemm_launch_t<bf16, 64, 64>(a, s);
+  const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
+  if (gemm_variant() == 0) return t128 >= 384 ? gemm_launch_t<T, 128, 128>(a, s) : gemm_launch_t<T, 64, 64>(a, s);
+  switch (gemm_variant()) {
+    case 2: return gemm_glds_launch_t<T, 64, 64, 2, 2, 4>(a, s);     // 4 waves, 32x32 per wave
+    case 3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
+    case 4: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4>(a, s);    // 8 waves, 32x32 per wave
+    case 5: return gemm_glds_launch_t<T, 128, 128, 2, 2, 3>(a, s);   // 4 waves, 64x64 per wave
+    case 6: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
+    case 7: return gemm_glds_launch_t<T, 32, 64, 2, 2, 4>(a, s);     // 4 waves, 16x32 per wave
+    case 8: return gemm_glds_launch_t<T, 64, 64, 2, 2, 6>(a, s);     // deeper ring
+    case 9: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 64, 2, 4, 4, 16>(a, s); break;   // 256-B rows
+    case 10: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 64, 2, 4, 3, 16>(a, s); break;
+    case 11: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3, 16>(a, s); break;
+    case 12: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 128, 2, 4, 3, 16>(a, s); break;
+    default: break;
   }
-  return use_big ? gemm_launch_t<float, 128, 128>(a, s) : gemm_launch_t<float, 64, 64>(a, s);
+  if (t128 >= 384) return gemm_glds_launch_t<T, 128, 128, 2, 2, 3>(a, s);
+  return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);   // 8 waves (2 per SIMD) hide the per-k-tile latency chain best
+}
+
+static hipError_t gemm_launch(const fdm_gemm_args& a, hipStream_t s) {
+  return a.dtype == FDM_BF16 ? gemm_dispatch<bf16>(a, s) : gemm_dispatch<float>(a, s);
 }
 
 }  // namespace fdm

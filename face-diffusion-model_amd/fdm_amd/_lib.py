@@ -32,14 +32,15 @@ class AttnArgs(C.Structure):
 class LnArgs(C.Structure):
     _fields_ = [("x", vp), ("M", ci), ("d", ci), ("add_mat", vp), ("add_tab", vp),
                 ("tab_index", vp), ("tab_step", vp), ("gamma", vp), ("beta", vp), ("eps", cf),
-                ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci)]
+                ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci), ("gamma2", vp), ("beta2", vp)]
 
 
 class SchedArgs(C.Structure):
     _fields_ = [("x0", vp), ("x0u", vp), ("cfg_scale", cf), ("x", vp), ("x_out", vp),
                 ("n", ll), ("n_per_clip", ll), ("tseq", vp), ("step", vp), ("advance", ci),
                 ("c1", vp), ("c2", vp), ("sigma", vp), ("sra", vp), ("srm1", vp),
-                ("sqrt_an", vp), ("c_n", vp), ("noise", vp), ("seed", C.c_ulonglong), ("clip0", ci),
+                ("sqrt_an", vp), ("c_n", vp), ("noise", vp), ("noise_stride", ll), ("x_out_t", vp), ("out_dtype", ci), ("arrive", vp),
+                ("seed", C.c_ulonglong), ("clip0", ci),
                 ("mode", ci)]
 
 
@@ -70,6 +71,7 @@ SYMBOLS = {
     "fdm_prog_instantiate": (ci, [vp, vp]),
     "fdm_prog_replay": (ci, [vp, ci, vp]),
     "fdm_prog_num_ops": (ci, [vp]),
+    "fdm_prog_set_lane": (ci, [vp, ci]),
 }
 
 _lib = None

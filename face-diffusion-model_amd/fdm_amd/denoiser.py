@@ -11,12 +11,15 @@ What runs where
     The cross-attention's memory mask leaves exactly one key per query (models/fdm_vocaset.py:119-127), so
     CA_l(h, AF + tau)[i] = C1_l[i] + TT_l[t] exactly (softmax over one key == 1).
   * step program (captured into one hipGraph, replayed T times; t comes from a device counter):
-      [cast x] -> latent_encoder GEMM(+bias+Mish+E0) -> 8 x { QKV GEMM (V scattered transposed) ->
-      fused causal-ALiBi attention -> out-proj GEMM(+bias+residual) -> LN1 -> LN2(+C1_l + TT_l[t]) ->
+      latent_encoder GEMM(+bias+Mish+E0) -> 8 x { QKV GEMM (V scattered transposed) ->
+      fused causal-ALiBi attention -> out-proj GEMM(+bias+residual) -> fused LN1+LN2(+C1_l + TT_l[t]) ->
       FFN1 GEMM(+bias+ReLU) -> FFN2 GEMM(+bias+residual) -> LN3 } -> latent_decoder GEMM ->
-      fused scheduler update (DDPM / DDIM, optional CFG mix, Philox or injected noise).
+      fused scheduler update (DDPM / DDIM, optional CFG mix, Philox or injected noise; also writes the
+      operand-dtype copy of x_{t-1} for the next step and advances the device-side step counter):
+      51 kernel launches per diffusion step.
 torch only owns the device buffers and the stream."""
 import math
+import os
 
 import torch
 
@@ -80,12 +83,19 @@ class DenoiserPlan:
         c1, c2, sg = schedule.ddpm_tables(schedule.make_buffers(1000))
         self.c1, self.c2, self.sigma = c1.to(dv), c2.to(dv), sg.to(dv)
         self.B = self.L = self.M = 0
+        self.default_chains = int(os.environ.get("FDM_CHAINS", "1"))
         self._progs = {}
         self._ddim = {}
 
     # ------------------------------------------------------------------------------------------
-    def prepare(self, hub, style, emo=None, L=None, cfg=False):
-        """hub [B, N, 1024] HuBERT features; style [B, n_style]; emo [B, n_emo]; L latent frames."""
+    def prepare(self, hub, style, emo=None, L=None, cfg=False, chains=None):
+        """hub [B, N, 1024] HuBERT features; style [B, n_style]; emo [B, n_emo]; L latent frames.
+
+        chains: number of independent clip groups.  Clips never interact, so the step program is recorded
+        as `chains` dependency-free chains (one per clip group) that the captured hipGraph runs as
+        parallel branches: at M = B*L of a few hundred rows every kernel is latency-bound, and
+        overlapping the chains hides launch gaps and per-kernel fill/drain.  Results are independent
+        of the grouping (per-clip arithmetic never depends on the batch composition)."""
         p, dv, d = self.p, self.device, self.p.d
         hub = _dev(hub, dv)
         B, N = hub.shape[0], hub.shape[1]
@@ -102,10 +112,20 @@ class DenoiserPlan:
             if emo.dim() == 1:
                 emo = emo.unsqueeze(0).expand(B, -1)
             emo = _dev(emo, dv)
+        if chains is None:
+            chains = self.default_chains
+        chains = max(1, min(int(chains), B))
+        while B % chains:
+            chains -= 1
         M = B * L
         self.B, self.L, self.M, self.cfg = B, L, M, bool(cfg)
+        self.chains, self.Bc, self.Mc = chains, B // chains, (B // chains) * L
+        self.rep = 2 if cfg else 1                    # row replication: cond rows then uncond rows, per chain
+        self.Rc = self.Mc * self.rep
+        self.R = self.Rc * chains
         self._progs = {}
         w = self.w32
+        Mc, Rc, Bc = self.Mc, self.Rc, self.Bc
         with torch.cuda.stream(self.stream):
             # audio rows: pair HuBERT frames (models/fdm_vqvae_mead.py:73), crop to L (:64-66)
             a = hub[:, : nfa * p.pair].reshape(B, nfa, p.pair * 1024)[:, :L].reshape(M, p.pair * 1024).contiguous()
@@ -114,44 +134,41 @@ class DenoiserPlan:
             ops.gemm(a, w["audio_extract.0.weight"], M, d, p.audio_in, bias=w["audio_extract.0.bias"], act=ACT_MISH, out_f32=t1)
             ops.gemm(t1, w["audio_extract.2.weight"], M, d, d, bias=w["audio_extract.2.bias"], out_f32=AF)
             self.AF = AF
-            # folded cross-attention tables C1_l [M, d]
+            # folded cross-attention tables C1_l, chain layout [chains][rep][Mc, d]
             self.C1 = []
+            c1 = torch.empty(M, d, device=dv)
             for l in range(p.n_layers):
-                c1 = torch.empty(M, d, device=dv)
                 ops.gemm(AF, self.Wv[l], M, d, d, bias=self.bv[l], out_f32=t1)
                 ops.gemm(t1, self.Wo[l], M, d, d, bias=self.bo[l], out_f32=c1)
-                self.C1.append(c1)
-            # conditioning addend E0 = PE[l] + style[b] (+ emotion[b])  (:75-84)
+                self.C1.append(c1.view(chains, 1, Mc, d).expand(chains, self.rep, Mc, d).reshape(self.R, d).clone())
+            # conditioning addend E0 = PE[l] + style[b] (+ emotion[b])  (:75-84), same chain layout
             sty = torch.empty(B, d, device=dv)
             ops.small_linear(style, w["style_embedd.weight"], w["style_embedd.bias"], sty, B, p.n_style, d,
                              ACT_MISH if p.style_mish else ACT_NONE)
-            rows = (2 * M) if cfg else M
-            self.E0 = torch.empty(rows, d, device=dv)
+            self.E0 = torch.empty(self.R, d, device=dv)
+            em = emu = None
             if p.n_emo:
                 em = torch.empty(B, d, device=dv)
                 ops.small_linear(emo, w["emotion_embedd.weight"], w["emotion_embedd.bias"], em, B, p.n_emo, d)
-                ops.add_rows(self.E0[:M], M, d, self.pe, 1, L, sty, L, B, em, L, B)
                 if cfg:   # null condition = zeros_like(emotion one-hot) (models/fdm_vqvae_mead.py:56-57) -> bias only
                     emu = torch.empty(B, d, device=dv)
                     ops.small_linear(torch.zeros_like(emo), w["emotion_embedd.weight"], w["emotion_embedd.bias"], emu, B, p.n_emo, d)
-                    ops.add_rows(self.E0[M:], M, d, self.pe, 1, L, sty, L, B, emu, L, B)
-            else:
-                ops.add_rows(self.E0[:M], M, d, self.pe, 1, L, sty, L, B)
-                if cfg:
-                    ops.add_rows(self.E0[M:], M, d, self.pe, 1, L, sty, L, B)
-            if cfg:
-                self.C1 = [torch.cat([c, c]) for c in self.C1]
+            for c in range(chains):
+                for r in range(self.rep):
+                    e = None if em is None else (emu if r == 1 else em)
+                    dst = self.E0[c * Rc + r * Mc:]
+                    if e is None:
+                        ops.add_rows(dst, Mc, d, self.pe, 1, L, sty[c * Bc:], L, Bc)
+                    else:
+                        ops.add_rows(dst, Mc, d, self.pe, 1, L, sty[c * Bc:], L, Bc, e[c * Bc:], L, Bc)
             self._alloc_workspace()
         self.stream.synchronize()
         return L
 
     def _alloc_workspace(self):
         p, dv, d = self.p, self.device, self.p.d
-        R = (2 * self.M) if self.cfg else self.M          # rows through the decoder stack
-        BB = (2 * self.B) if self.cfg else self.B
-        td = self.td
+        R, td = self.R, self.td
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dv, dtype=dt)
-        self.R, self.BB = R, BB
         self.Lpad = (self.L + 31) // 32 * 32
         ws = dict(h=z(R, d), h2=z(R, d), x1=z(R, d), x0=z(R, d), x=z(self.M, d))
         if self.dtype == BF16:
@@ -159,70 +176,92 @@ class DenoiserPlan:
         else:   # fp32 operands alias the fp32 residual-stream buffers
             ws.update(xt=ws["x"], ht=ws["h"], h2t=ws["h2"])
         ws.update(qkv=z(R, 3 * d, dt=td), ctx=z(R, d, dt=td), u=z(R, p.ffn, dt=td),
-                  vt=z(BB * p.n_head, p.head_dim, self.Lpad, dt=td))
+                  vt=z(self.B * self.rep * p.n_head, p.head_dim, self.Lpad, dt=td))
         self.ws = ws
-        self.step = torch.zeros(1, dtype=torch.int32, device=dv)
+        self.step = torch.zeros(self.chains, dtype=torch.int32, device=dv)      # one device-side step counter per chain
+        self.arrive = torch.zeros(self.chains, dtype=torch.int32, device=dv)    # ticket words of the in-kernel advance
         self.tseq = torch.zeros(1024, dtype=torch.int32, device=dv)
 
     # ------------------------------------------------------------------------------------------
-    def _record_pass(self):
-        """Record one denoiser pass: ws['x'] (fp32 [M, d]) -> ws['x0'] ([R, d], cond rows then uncond rows)."""
-        p, d, M, R, ws, w, wt = self.p, self.p.d, self.M, self.R, self.ws, self.w32, self.wt
+    def _record_chain(self, c):
+        """Record the denoiser pass of clip group c: ws['x'] rows of the group -> ws['x0'] rows of the group."""
+        p, d, ws, w, wt = self.p, self.p.d, self.ws, self.w32, self.wt
+        Mc, Rc, Bc, L = self.Mc, self.Rc, self.Bc, self.L
+        xr, rb = c * Mc, c * Rc                         # first row of the group in x / in the decoder-stack buffers
         both = self.dtype == BF16
-        if both:
-            ops.cast(ws["x"], ws["xt"])
-        for half in range(2 if self.cfg else 1):
-            o = half * M
-            ops.gemm(ws["xt"], wt["latent_encoder.0.weight"], M, d, d, bias=w["latent_encoder.0.bias"],
+        step = self.step[c:]
+        # (the operand-dtype copy ws['xt'] of x is written by the scheduler kernel of the previous step and by
+        #  _load_x() before the first one)
+        for r in range(self.rep):
+            o = rb + r * Mc
+            ops.gemm(ws["xt"][xr:], wt["latent_encoder.0.weight"], Mc, d, d, bias=w["latent_encoder.0.bias"],
                      act=ACT_MISH if p.latent_mish else ACT_NONE, resid=self.E0[o:], out_f32=ws["h"][o:],
                      out_t=ws["ht"][o:] if both else None)
+        BBc = Bc * self.rep
+        vt = ws["vt"][c * BBc * p.n_head:]
         for l in range(p.n_layers):
             pre = f"transformer_decoder.layers.{l}."
-            ops.gemm(ws["ht"], wt[pre + "self_attn.in_proj_weight"], R, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"],
-                     out_t=ws["qkv"], ldo_t=3 * d, out_vt=ws["vt"], vt_col0=2 * d, vt_L=self.L, vt_Lpad=self.Lpad,
-                     vt_hd=p.head_dim)
-            ops.attention(ws["qkv"], ws["qkv"][:, d:], ws["vt"], ws["ctx"], B=self.BB, H=p.n_head, L=self.L, hd=p.head_dim,
+            ops.gemm(ws["ht"][rb:], wt[pre + "self_attn.in_proj_weight"], Rc, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"],
+                     out_t=ws["qkv"][rb:], ldo_t=3 * d, out_vt=vt, vt_col0=2 * d, vt_L=L, vt_Lpad=self.Lpad, vt_hd=p.head_dim)
+            ops.attention(ws["qkv"][rb:], ws["qkv"][rb:, d:], vt, ws["ctx"][rb:], B=BBc, H=p.n_head, L=L, hd=p.head_dim,
                           ldq=3 * d, ldk=3 * d, ldo=d, Lpad=self.Lpad, scale=1.0 / math.sqrt(p.head_dim), causal=True,
                           slopes=self.slopes, period=p.period)
-            ops.gemm(ws["ctx"], wt[pre + "self_attn.out_proj.weight"], R, d, d, bias=w[pre + "self_attn.out_proj.bias"],
-                     resid=ws["h"], out_f32=ws["x1"])
-            ops.layernorm(ws["x1"], w[pre + "norm1.weight"], w[pre + "norm1.bias"], R, d, y_f32=ws["h"])
-            ops.layernorm(ws["h"], w[pre + "norm2.weight"], w[pre + "norm2.bias"], R, d, add_mat=self.C1[l],
-                          add_tab=self.TT[l], tab_index=self.tseq, tab_step=self.step, y_f32=ws["h2"],
-                          y_t=ws["h2t"] if both else None, dtype=self.dtype)
-            ops.gemm(ws["h2t"], wt[pre + "linear1.weight"], R, p.ffn, d, bias=w[pre + "linear1.bias"], act=ACT_RELU,
-                     out_t=ws["u"])
-            ops.gemm(ws["u"], wt[pre + "linear2.weight"], R, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"],
-                     out_f32=ws["x1"])
-            ops.layernorm(ws["x1"], w[pre + "norm3.weight"], w[pre + "norm3.bias"], R, d, y_f32=ws["h"],
-                          y_t=ws["ht"] if both else None, dtype=self.dtype)
-        ops.gemm(ws["ht"], wt["latent_decoder.weight"], R, d, d, bias=w["latent_decoder.bias"], out_f32=ws["x0"])
+            ops.gemm(ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
+                     resid=ws["h"][rb:], out_f32=ws["x1"][rb:])
+            # norm1 and norm2 back to back in one kernel: h2 = LN2(LN1(x1) + C1_l + TT_l[t])
+            ops.layernorm(ws["x1"][rb:], w[pre + "norm1.weight"], w[pre + "norm1.bias"], Rc, d, add_mat=self.C1[l][rb:],
+                          add_tab=self.TT[l], tab_index=self.tseq, tab_step=step, y_f32=ws["h2"][rb:],
+                          y_t=ws["h2t"][rb:] if both else None, dtype=self.dtype,
+                          gamma2=w[pre + "norm2.weight"], beta2=w[pre + "norm2.bias"])
+            ops.gemm(ws["h2t"][rb:], wt[pre + "linear1.weight"], Rc, p.ffn, d, bias=w[pre + "linear1.bias"], act=ACT_RELU,
+                     out_t=ws["u"][rb:])
+            ops.gemm(ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
+                     out_f32=ws["x1"][rb:])
+            ops.layernorm(ws["x1"][rb:], w[pre + "norm3.weight"], w[pre + "norm3.bias"], Rc, d, y_f32=ws["h"][rb:],
+                          y_t=ws["ht"][rb:] if both else None, dtype=self.dtype)
+        ops.gemm(ws["ht"][rb:], wt["latent_decoder.weight"], Rc, d, d, bias=w["latent_decoder.bias"], out_f32=ws["x0"][rb:])
 
     def _program(self, kind, **kw):
-        """Build (once) the step program `kind` in {'pass', 'ddpm', 'ddim'}."""
+        """Build (once) the step program `kind` in {'pass', 'ddpm', 'ddim'}: one lane per clip group."""
         key = (kind,) + tuple(sorted((k, (v.data_ptr() if torch.is_tensor(v) else v)) for k, v in kw.items()))
         if key in self._progs:
             return self._progs[key]
-        n = self.M * self.p.d
-        ws = self.ws
+        d, ws, Mc, Rc = self.p.d, self.ws, self.Mc, self.Rc
+        n = Mc * d
         prog = ops.Program()
         with prog:
-            self._record_pass()
-            x0u = ws["x0"][self.M:] if self.cfg else None
-            if kind == "ddpm":
-                ops.sched_step(0, ws["x0"], ws["x"], ws["x"], n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
-                               n_per_clip=self.L * self.p.d, tseq=self.tseq, step=self.step, advance=1,
-                               c1=self.c1, c2=self.c2, sigma=self.sigma, noise=kw.get("noise"), seed=kw.get("seed", 0),
-                               clip0=kw.get("clip0", 0))
-            elif kind == "ddim":
-                ops.sched_step(1, ws["x0"], ws["x"], ws["x"], n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
-                               tseq=self.tseq, step=self.step, advance=1, sra=self.buf["sqrt_recip_alphas_cumprod"],
-                               srm1=self.buf["sqrt_recipm1_alphas_cumprod"], sqrt_an=kw["sqrt_an"], c_n=kw["c_n"])
-            elif kind == "pass" and self.cfg:
-                ops.sched_step(2, ws["x0"], None, ws["x0"], n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0))
+            for c in range(self.chains):
+                prog.lane(c)
+                self._record_chain(c)
+                x0 = ws["x0"][c * Rc:]
+                x0u = ws["x0"][c * Rc + Mc:] if self.cfg else None
+                x = ws["x"][c * Mc:]
+                xt = ws["xt"][c * Mc:] if self.dtype == BF16 else None
+                step = self.step[c:]
+                arrive = self.arrive[c:]
+                if kind == "ddpm":
+                    nz = kw.get("noise")
+                    ops.sched_step(0, x0, x, x, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
+                                   n_per_clip=self.L * d, tseq=self.tseq, step=step, advance=1,
+                                   c1=self.c1, c2=self.c2, sigma=self.sigma,
+                                   noise=None if nz is None else nz.view(-1)[c * n:], noise_stride=self.M * d,
+                                   seed=kw.get("seed", 0), clip0=kw.get("clip0", 0) + c * self.Bc, x_out_t=xt, arrive=arrive)
+                elif kind == "ddim":
+                    ops.sched_step(1, x0, x, x, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
+                                   tseq=self.tseq, step=step, advance=1, sra=self.buf["sqrt_recip_alphas_cumprod"],
+                                   srm1=self.buf["sqrt_recipm1_alphas_cumprod"], sqrt_an=kw["sqrt_an"], c_n=kw["c_n"],
+                                   x_out_t=xt, arrive=arrive)
+                elif kind == "pass" and self.cfg:
+                    ops.sched_step(2, x0, None, x0, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0))
         prog.hold(*[v for v in kw.values() if torch.is_tensor(v)])
         self._progs[key] = prog
         return prog
+
+    def _x0_rows(self):
+        """The (cond / CFG-mixed) x0 rows in clip order [M, d]."""
+        if self.rep == 1:
+            return self.ws["x0"]
+        return self.ws["x0"].view(self.chains, self.rep, self.Mc, self.p.d)[:, 0].reshape(self.M, self.p.d)
 
     def _set_steps(self, ts):
         if len(ts) > self.tseq.numel():
@@ -230,6 +269,12 @@ class DenoiserPlan:
             self._progs = {}
         self.tseq[: len(ts)].copy_(torch.tensor(ts, dtype=torch.int32))
         self.step.zero_()
+        self.arrive.zero_()
+
+    def _load_x(self, x):
+        self.ws["x"].copy_(x.reshape(self.M, self.p.d))
+        if self.dtype == BF16:
+            ops.cast(self.ws["x"], self.ws["xt"])
 
     def _run(self, prog, n_steps, use_graph):
         if use_graph:
@@ -246,10 +291,10 @@ class DenoiserPlan:
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            self.ws["x"].copy_(x.reshape(self.M, self.p.d))
+            self._load_x(x)
             self._set_steps([int(t)])
             self._program("pass", cfg_scale=float(cfg_scale)).run()
-            out = self.ws["x0"][: self.M].clone().reshape(x.shape)
+            out = self._x0_rows().clone().reshape(x.shape)
         cur.wait_stream(self.stream)
         return out
 
@@ -266,7 +311,7 @@ class DenoiserPlan:
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            self.ws["x"].copy_(x_T.reshape(self.M, self.p.d))
+            self._load_x(x_T)
             self._set_steps(list(t_list))
             kw = dict(cfg_scale=float(cfg_scale), clip0=int(clip0))
             if noise is not None:
@@ -296,7 +341,7 @@ class DenoiserPlan:
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
-            self.ws["x"].copy_(x_T.reshape(self.M, self.p.d))
+            self._load_x(x_T)
             self._set_steps([pr[0] for pr in pairs])
             prog = self._program("ddim", cfg_scale=float(cfg_scale), sqrt_an=san, c_n=cn)
             self._run(prog, len(pairs), use_graph)

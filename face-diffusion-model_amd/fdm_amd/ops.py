@@ -63,21 +63,25 @@ def attention(Q, K, Vt, O, *, B, H, L, hd, ldq, ldk, ldo, Lpad, scale, causal=Fa
 
 
 def layernorm(x, gamma, beta, M, d, *, add_mat=None, add_tab=None, tab_index=None, tab_step=None, eps=1e-5,
-              act=ACT_NONE, y_f32=None, y_t=None, dtype=F32):
+              act=ACT_NONE, y_f32=None, y_t=None, dtype=F32, gamma2=None, beta2=None):
     a = LnArgs()
     a.x, a.M, a.d, a.add_mat, a.add_tab = _p(x), M, d, _p(add_mat), _p(add_tab)
     a.tab_index, a.tab_step, a.gamma, a.beta, a.eps = _p(tab_index), _p(tab_step), _p(gamma), _p(beta), eps
     a.act, a.y_f32, a.y_t, a.dtype = act, _p(y_f32), _p(y_t), dtype
+    a.gamma2, a.beta2 = _p(gamma2), _p(beta2)
     check(lib().fdm_op_layernorm(C.byref(a), stream()))
 
 
 def sched_step(mode, x0, x, x_out, n, *, x0u=None, cfg_scale=0.0, n_per_clip=0, tseq=None, step=None, advance=0,
-               c1=None, c2=None, sigma=None, sra=None, srm1=None, sqrt_an=None, c_n=None, noise=None, seed=0, clip0=0):
+               c1=None, c2=None, sigma=None, sra=None, srm1=None, sqrt_an=None, c_n=None, noise=None, noise_stride=0,
+               seed=0, clip0=0, x_out_t=None, arrive=None):
     a = SchedArgs()
     a.x0, a.x0u, a.cfg_scale, a.x, a.x_out = _p(x0), _p(x0u), cfg_scale, _p(x), _p(x_out)
     a.n, a.n_per_clip, a.tseq, a.step, a.advance = n, n_per_clip, _p(tseq), _p(step), advance
     a.c1, a.c2, a.sigma, a.sra, a.srm1 = _p(c1), _p(c2), _p(sigma), _p(sra), _p(srm1)
-    a.sqrt_an, a.c_n, a.noise, a.seed, a.clip0, a.mode = _p(sqrt_an), _p(c_n), _p(noise), seed, clip0, mode
+    a.sqrt_an, a.c_n, a.noise, a.noise_stride = _p(sqrt_an), _p(c_n), _p(noise), noise_stride
+    a.seed, a.clip0, a.mode = seed, clip0, mode
+    a.x_out_t, a.out_dtype, a.arrive = _p(x_out_t), (code_of(x_out_t) if x_out_t is not None else 0), _p(arrive)
     check(lib().fdm_op_sched_step(C.byref(a), stream()))
 
 
@@ -148,6 +152,10 @@ class Program:
         if et is None:
             check(rc)
         return False
+
+    def lane(self, i):
+        """Subsequent ops belong to independent chain i (a parallel branch of the captured graph)."""
+        check(lib().fdm_prog_set_lane(self.h, i))
 
     def hold(self, *tensors):
         self.keep.extend(tensors)

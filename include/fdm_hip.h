@@ -101,6 +101,10 @@ typedef struct fdm_ln_args {
   const float* gamma; const float* beta; float eps;
   int act;
   float* y_f32; void* y_t; int dtype;
+  /* optional fused second LayerNorm (post-norm decoder: norm1 then norm2 back to back,
+   * models/fdm_vocaset.py:45): y = LN2(LN1(x) + add_mat + add_tab[idx]); the addends then belong to
+   * stage 2 and stage 1 sees x alone. */
+  const float* gamma2; const float* beta2;
 } fdm_ln_args;
 int fdm_op_layernorm(const fdm_ln_args* a, void* stream);
 
@@ -122,7 +126,11 @@ typedef struct fdm_sched_args {
   const float* c1; const float* c2; const float* sigma;      /* DDPM tables, indexed by t */
   const float* sra; const float* srm1;                       /* DDIM tables, indexed by t */
   const float* sqrt_an; const float* c_n;                    /* DDIM tables, indexed by step k */
-  const float* noise; unsigned long long seed; int clip0;
+  const float* noise; long long noise_stride;               /* elements between steps (0 -> n) */
+  void* x_out_t; int out_dtype;                              /* optional operand-dtype copy of x_out (next step's GEMM input) */
+  unsigned int* arrive;                                      /* device word (zeroed once): lets the LAST block to read *step
+                                                                advance it inside this kernel (no separate launch) */
+  unsigned long long seed; int clip0;
   int mode;                                                  /* 0 DDPM, 1 DDIM, 2 CFG mix only (x_out = mix) */
 } fdm_sched_args;
 int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
@@ -170,6 +178,12 @@ int fdm_prog_run(fdm_prog* p, void* stream);                 /* eager: launch ev
 int fdm_prog_instantiate(fdm_prog* p, void* stream);         /* capture into a hipGraph */
 int fdm_prog_replay(fdm_prog* p, int n, void* stream);       /* launch the graph n times */
 int fdm_prog_num_ops(fdm_prog* p);
+/* While recording: tag subsequent ops with an independent lane (chain).  Clips are independent, so the
+ * per-clip-group chains of a step carry no mutual dependencies; fdm_prog_instantiate captures one
+ * hipGraph per lane and fdm_prog_replay launches them on per-lane internal streams (forked from and
+ * joined into the caller's stream once per replay call), so the chains' kernels overlap on the
+ * device.  fdm_prog_run executes all ops in program order on the caller's stream. */
+int fdm_prog_set_lane(fdm_prog* p, int lane);
 
 #ifdef __cplusplus
 }

@@ -87,7 +87,7 @@ def test_cfg_two_pass_mix_vs_golden(golden):
     plan.prepare(inp["hub"], inp["style"], inp["emo"], L=L, cfg=True)
     out = plan.denoise(inp["x"].to(DEV), t, cfg_scale=2.5)
     assert mad(out[0], g["mix"]) < TOL32
-    assert mad(plan.ws["x0"][plan.M:].reshape(1, -1, 64)[0], g["uncond"]) < TOL32
+    assert mad(plan.ws["x0"][plan.Mc:plan.Rc].reshape(-1, 64), g["uncond"]) < TOL32
 
 
 @pytest.mark.parametrize("preset,dtype", [("vocaset", F32), ("mead", F32), ("vocaset", BF16)])

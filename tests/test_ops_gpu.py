@@ -291,3 +291,42 @@ def test_program_record_graph_replay():
     s.synchronize()
     assert int(step[0]) == 10
     assert float(x[0]) == float(sum(3 * k for k in range(10)))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_fused_double_layernorm(dtype):
+    g = torch.Generator().manual_seed(77)
+    M, d = 301, 1024
+    x = torch.randn(M, d, generator=g) * 3
+    am = torch.randn(M, d, generator=g)
+    tab = torch.randn(4, d, generator=g)
+    g1, b1, g2, b2 = [torch.randn(d, generator=g) * 0.1 + (1 if i % 2 == 0 else 0) for i in range(4)]
+    ref = F.layer_norm(F.layer_norm(x, (d,), g1, b1, 1e-5) + (am + tab[2]), (d,), g2, b2, 1e-5)
+    tidx = torch.tensor([2], dtype=torch.int32, device=DEV)
+    y32 = torch.zeros(M, d, device=DEV)
+    yt = torch.zeros(M, d, device=DEV, dtype=ops.tdtype(dtype))
+    ops.layernorm(x.to(DEV), g1.to(DEV), b1.to(DEV), M, d, add_mat=am.to(DEV), add_tab=tab.to(DEV), tab_index=tidx,
+                  y_f32=y32, y_t=yt, dtype=dtype, gamma2=g2.to(DEV), beta2=b2.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(y32, ref) < 1e-5
+    assert rel(yt.float(), ref) < (1e-5 if dtype == F32 else 1e-2)
+
+
+def test_sched_in_kernel_advance_and_operand_copy():
+    n = 256 * 1024 * 4        # many blocks: exercises the last-ticket advance
+    x0 = torch.randn(n, device=DEV)
+    x = torch.randn(n, device=DEV)
+    one = torch.ones(1000, device=DEV)
+    zero = torch.zeros(1000, device=DEV)
+    tseq = torch.arange(10, dtype=torch.int32, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    arrive = torch.zeros(1, dtype=torch.int32, device=DEV)
+    out = torch.zeros(n, device=DEV)
+    outt = torch.zeros(n, device=DEV, dtype=torch.bfloat16)
+    noise = torch.zeros(5, n, device=DEV)
+    for k in range(5):
+        ops.sched_step(0, x0, x, out, n, tseq=tseq, step=step, advance=1, c1=one, c2=one, sigma=zero, noise=noise,
+                       x_out_t=outt, arrive=arrive)
+        torch.cuda.synchronize()
+        assert int(step[0]) == k + 1 and int(arrive[0]) == 0
+    assert torch.equal(out, x0 + x) and torch.equal(outt, (x0 + x).to(torch.bfloat16))
