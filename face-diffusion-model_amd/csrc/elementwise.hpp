@@ -135,10 +135,12 @@ __device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigne
   const float k = 2.3283064365386963e-10f;  // 2^-32
   const float u0 = ((float)r[0] + 0.5f) * k, u1 = (float)r[1] * k;
   const float u2 = ((float)r[2] + 0.5f) * k, u3 = (float)r[3] * k;
-  const float ra = sqrtf(-2.f * logf(fminf(u0, 1.f))), rb = sqrtf(-2.f * logf(fminf(u2, 1.f)));
-  float s0, c0, s1, c1;
-  sincosf(6.283185307179586f * u1, &s0, &c0);
-  sincosf(6.283185307179586f * u3, &s1, &c1);
+  // hardware log2 / sin / cos (v_log_f32, v_sin_f32, v_cos_f32 take the angle in turns): the noise is a
+  // sampling input, not a parity surface, and the accurate libm forms made this kernel VALU-bound
+  const float ra = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(fminf(u0, 1.f)));   // -2 ln u = -2 ln2 log2 u
+  const float rb = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(fminf(u2, 1.f)));
+  const float s0 = __builtin_amdgcn_sinf(u1), c0 = __builtin_amdgcn_cosf(u1);
+  const float s1 = __builtin_amdgcn_sinf(u3), c1 = __builtin_amdgcn_cosf(u3);
   return f32x4{ra * c0, ra * s0, rb * c1, rb * s1};
 }
 
