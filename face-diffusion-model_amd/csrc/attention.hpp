@@ -1,7 +1,10 @@
 // Fused attention for short sequences (L <= ~1500, head_dim 64 / 128) on gfx950 MFMA.
 //
-// One wavefront owns 16 query rows of one (clip, head) and walks the key tiles with an online
-// softmax; no LDS, no barriers (K and V^T tiles are a few KB per head and L2-resident).
+// One workgroup (4 wavefronts) owns 16 query rows of one (clip, head).  The key tiles are dealt
+// round-robin to the 4 waves, each running its own online softmax straight from L2 (K and V^T tiles
+// are a few KB per head), and the four partial (m, l, O) states are merged through LDS at the end:
+// with L <= 600 a query tile has at most 19 key tiles, so the per-wave dependent chain is <= 5 tiles
+// instead of 19 -- these kernels are latency-bound, not FLOP-bound.
 //
 // "Swapped" formulation so that nothing has to be transposed between the two products:
 //   S^T[key][query] = K * Q^T      A-port rows = keys,   B-port cols = queries
@@ -38,11 +41,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, r16 = lane & 15;
-  const int qt = blockIdx.x * 4 + wave;
+  const int qt = blockIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
   const int L = p.L;
   const int q0 = qt * 16;
-  if (q0 >= L) return;
+  __shared__ __attribute__((aligned(16))) float part_o[4][16][HD];
+  __shared__ float part_m[4][16], part_l[4][16];
 
   const T* Q = (const T*)p.Q + (size_t)b * L * p.ldq + (size_t)h * HD;
   const T* K = (const T*)p.K + (size_t)b * L * p.ldk + (size_t)h * HD;
@@ -78,15 +82,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
     }
   };
   u32x4 kcur[NSUB][NKS], knext[NSUB][NKS];
-  load_k(0, kcur);
+  if (wave < ntiles) load_k(wave, kcur);
   const float inv_period = 1.f / (float)p.period;
 
-  for (int kt = 0; kt < ntiles; ++kt) {
+  for (int kt = wave; kt < ntiles; kt += 4) {
     const int kbase = kt * KT;
     u32x4 vf[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) vf[c] = *(const u32x4*)(Vt + (size_t)(c * 16 + r16) * p.Lpad + kbase + g * EPC);
-    if (kt + 1 < ntiles) load_k(kt + 1, knext);
+    if (kt + 4 < ntiles) load_k(kt + 4, knext);
     f32x4 sc[NSUB];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
@@ -149,25 +153,44 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
   float l_tot = l_part;
   l_tot += __shfl_xor(l_tot, 16, 64);
   l_tot += __shfl_xor(l_tot, 32, 64);
-  const float inv = 1.f / l_tot;
-  if (qi < L) {
-    T* op = (T*)p.O + ((size_t)b * L + qi) * p.ldo + (size_t)h * HD;
+  // ---- merge the four waves' partial states ----
+  if (g == 0) { part_m[wave][r16] = m_run; part_l[wave][r16] = l_tot; }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      f32x4 v = o[c] * inv;
-      if constexpr (sizeof(T) == 4) {
-        *(f32x4*)(op + c * 16 + 4 * g) = v;
-      } else {
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-        bf16x4 ob = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-        *(bf16x4*)(op + c * 16 + 4 * g) = ob;
+  for (int c = 0; c < NC; ++c) *(f32x4*)&part_o[wave][r16][c * 16 + 4 * g] = o[c];
+  __syncthreads();
+  {
+    const int q = threadIdx.x >> 4;                  // 16 threads per query row
+    const int e0 = (threadIdx.x & 15) * (HD / 16);   // HD/16 consecutive head-dim elements per thread
+    const int qq = q0 + q;
+    float mw[4], ms = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { mw[w] = part_m[w][q]; ms = fmaxf(ms, mw[w]); }
+    float sw[4], lsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { sw[w] = fexp<T>(mw[w] - ms); lsum += sw[w] * part_l[w][q]; }   // exp(-inf) = 0 for idle waves
+    const float inv = 1.f / lsum;
+    if (qq < L) {
+      T* op = (T*)p.O + ((size_t)b * L + qq) * p.ldo + (size_t)h * HD + e0;
+#pragma unroll
+      for (int j = 0; j < HD / 16; j += 4) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += *(const f32x4*)&part_o[w][q][e0 + j] * sw[w];
+        v *= inv;
+        if constexpr (sizeof(T) == 4) {
+          *(f32x4*)(op + j) = v;
+        } else {
+          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+          bf16x4 ob = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4*)(op + j) = ob;
+        }
       }
     }
   }
 }
 
 static hipError_t attn_launch(const fdm_attn_args& a, hipStream_t s) {
-  dim3 grid((a.L + 63) / 64, a.H, a.B);
+  dim3 grid((a.L + 15) / 16, a.H, a.B);
   dim3 block(256);
   if (a.dtype == FDM_BF16) {
     if (a.hd == 128) hipLaunchKernelGGL((attn_kernel<bf16, 128>), grid, block, 0, s, a);

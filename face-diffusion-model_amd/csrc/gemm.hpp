@@ -350,8 +350,12 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case 12: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 128, 2, 4, 3, 16>(a, s); break;
     default: break;
   }
-  if (t128 >= 384) return gemm_glds_launch_t<T, 128, 128, 2, 2, 3>(a, s);
-  return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);   // 8 waves (2 per SIMD) hide the per-k-tile latency chain best
+  // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;
+  // below that the 64x64 tile's extra blocks beat its higher L2->LDS traffic.
+  const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
+  if (t128 >= 512) return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
+  if (t128x64 >= 700) return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);  // 8 waves, 32x32 per wave
+  return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                       // 8 waves, 32x16 per wave
 }
 
 static hipError_t gemm_launch(const fdm_gemm_args& a, hipStream_t s) {

@@ -25,7 +25,7 @@ def timeit(fn, n_rec=20, reps=20):
 
 def main():
     dt = torch.bfloat16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else torch.float32
-    M, d, ffn = 800, 1024, 2048
+    M, d, ffn = (int(sys.argv[2]) if len(sys.argv) > 2 else 800), 1024, 2048
     shapes = [('fixed-overhead K=64', M, d, 64), ('enc/dec/out-proj', M, d, d), ('qkv', M, 3 * d, d), ('ffn1', M, ffn, d), ('ffn2', M, d, ffn)]
     for name, m, n, k in shapes:
         A = torch.randn(m, k, device=DEV).to(dt); W = (torch.randn(n, k, device=DEV) / math.sqrt(k)).to(dt)
@@ -34,6 +34,7 @@ def main():
         us = timeit(lambda: ops.gemm(A, W, m, n, k, bias=bias, resid=res, out_f32=o32))
         fl = 2.0 * m * n * k
         print(f"gemm {name:18s} M={m} N={n} K={k}: {us:7.2f} us  {fl / us / 1e6:7.1f} TFLOP/s")
+    if len(sys.argv) > 2: return
     B, H, L, hd = 4, 8, 200, 128
     Lpad = 224
     qkv = torch.randn(M, 3 * d, device=DEV).to(dt); vt = torch.randn(B * H, hd, Lpad, device=DEV).to(dt)
