@@ -193,10 +193,12 @@ static hipError_t attn_launch(const fdm_attn_args& a, hipStream_t s) {
   dim3 grid((a.L + 15) / 16, a.H, a.B);
   dim3 block(256);
   if (a.dtype == FDM_BF16) {
-    if (a.hd == 128) hipLaunchKernelGGL((attn_kernel<bf16, 128>), grid, block, 0, s, a);
+    if (a.hd == 256) hipLaunchKernelGGL((attn_kernel<bf16, 256>), grid, block, 0, s, a);
+    else if (a.hd == 128) hipLaunchKernelGGL((attn_kernel<bf16, 128>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<bf16, 64>), grid, block, 0, s, a);
   } else {
-    if (a.hd == 128) hipLaunchKernelGGL((attn_kernel<float, 128>), grid, block, 0, s, a);
+    if (a.hd == 256) hipLaunchKernelGGL((attn_kernel<float, 256>), grid, block, 0, s, a);
+    else if (a.hd == 128) hipLaunchKernelGGL((attn_kernel<float, 128>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((attn_kernel<float, 64>), grid, block, 0, s, a);
   }
   return hipGetLastError();

@@ -106,7 +106,7 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
 
 int fdm_op_attention(const fdm_attn_args* a, void* stream) {
   if (!a || !a->Q || !a->K || !a->Vt || !a->O) return fail(FDM_ERR_ARG, "attention: null operand");
-  if (a->hd != 64 && a->hd != 128) return fail(FDM_ERR_SHAPE, "attention: head_dim %d unsupported (64, 128)", a->hd);
+  if (a->hd != 64 && a->hd != 128 && a->hd != 256) return fail(FDM_ERR_SHAPE, "attention: head_dim %d unsupported (64, 128, 256)", a->hd);
   if (a->B <= 0 || a->H <= 0 || a->L <= 0) return fail(FDM_ERR_SHAPE, "attention: B,H,L must be positive");
   if (a->Lpad < a->L || a->Lpad % 32) return fail(FDM_ERR_SHAPE, "attention: Lpad=%d must be a multiple of 32 >= L", a->Lpad);
   const int epc = a->dtype == FDM_BF16 ? 8 : 4;

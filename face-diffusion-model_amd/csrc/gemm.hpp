@@ -344,6 +344,8 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case 6: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
     case 7: return gemm_glds_launch_t<T, 32, 64, 2, 2, 4>(a, s);     // 4 waves, 16x32 per wave
     case 8: return gemm_glds_launch_t<T, 64, 64, 2, 2, 6>(a, s);     // deeper ring
+    case 13: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);    // 3 stages: 48 KB LDS -> 3 blocks per CU
+    case 14: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 2 stages: 32 KB LDS -> 5 blocks per CU
     case 9: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 64, 2, 4, 4, 16>(a, s); break;   // 256-B rows
     case 10: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 64, 2, 4, 3, 16>(a, s); break;
     case 11: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3, 16>(a, s); break;

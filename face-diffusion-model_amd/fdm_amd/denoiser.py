@@ -38,8 +38,8 @@ class DenoiserPlan:
         self.device = torch.device(device)
         self.td = ops.tdtype(dtype)
         p, dv = self.p, self.device
-        if p.head_dim != 128:
-            raise FdmError("denoiser head_dim must be 128")
+        if p.head_dim not in (64, 128, 256):
+            raise FdmError(f"denoiser head_dim {p.head_dim} unsupported (64, 128, 256)")
         self.stream = torch.cuda.Stream(device=dv)
         w = {k: _dev(v, dv) for k, v in weights.items() if not k.startswith("audio_encoder.") and k != "PE.pe"}
         self.w32 = w
@@ -128,7 +128,10 @@ class DenoiserPlan:
         Mc, Rc, Bc = self.Mc, self.Rc, self.Bc
         with torch.cuda.stream(self.stream):
             # audio rows: pair HuBERT frames (models/fdm_vqvae_mead.py:73), crop to L (:64-66)
-            a = hub[:, : nfa * p.pair].reshape(B, nfa, p.pair * 1024)[:, :L].reshape(M, p.pair * 1024).contiguous()
+            fw = hub.shape[2]                      # 1024 (HuBERT-large) or 768 (wav2vec2-base, BIWI)
+            if p.pair * fw != p.audio_in:
+                raise FdmError(f"audio feature width {fw} x pair {p.pair} != audio_extract input {p.audio_in}")
+            a = hub[:, : nfa * p.pair].reshape(B, nfa, p.pair * fw)[:, :L].reshape(M, p.pair * fw).contiguous()
             t1 = torch.empty(M, d, device=dv)
             AF = torch.empty(M, d, device=dv)
             ops.gemm(a, w["audio_extract.0.weight"], M, d, p.audio_in, bias=w["audio_extract.0.bias"], act=ACT_MISH, out_f32=t1)

@@ -119,8 +119,8 @@ class _FDMBase(ParamTree):
         base = presets.get(self.preset_name)
         self.preset = replace(base, name=f"{base.name}_d{feature_dim}", d=feature_dim, n_head=n_head, n_layers=num_layers,
                               ffn=2 * feature_dim, c=feature_dim // base.G)
-        if self.preset.head_dim != 128:
-            raise FdmError(f"feature_dim/n_head = {self.preset.head_dim}: the HIP attention kernel supports head_dim 128")
+        if self.preset.head_dim not in (64, 128, 256):
+            raise FdmError(f"feature_dim/n_head = {self.preset.head_dim}: the HIP attention kernel supports head_dim 64/128/256")
         self.struct = struct
         presets.PRESETS[self.preset.name] = self.preset
         for k, v in synth.make_fdm_weights(self.preset.name).items():
@@ -223,7 +223,7 @@ class FDMBiwi(_FDMBase):
     """BIWI denoiser (build-defined semantics: 'Dec' struct, latent regrouped x8; parity unpinned vs reference)."""
     preset_name = "biwi"
 
-    def __init__(self, feature_dim=1024, vertice_dim=70110, n_head=8, num_layers=8, struct="Dec", dtype=None, audio_encoder=False):
+    def __init__(self, feature_dim=1024, vertice_dim=70110, n_head=4, num_layers=8, struct="Dec", dtype=None, audio_encoder=False):
         super().__init__()
         self._build(feature_dim, n_head, num_layers, struct, dtype, audio_encoder)
 

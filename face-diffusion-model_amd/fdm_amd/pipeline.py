@@ -48,7 +48,7 @@ def build_models(preset="vocaset", feature_dim=None, device="cuda:0", stage1=Non
     from dropin_config import vq_args_for
     p = presets.get(preset)
     cls = {"vocaset": FDM, "mead": FDMMead, "biwi": FDMBiwi}[p.name]
-    kw = dict(feature_dim=feature_dim or p.d, n_head=(feature_dim or p.d) // 128, dtype=dtype)
+    kw = dict(feature_dim=feature_dim or p.d, n_head=(feature_dim or p.d) // p.head_dim, dtype=dtype)
     model = cls(**kw)
     ae = VQAutoEncoder(vq_args_for(p.name), dtype=dtype)
     denoise = ClassifierFreeSampleModel(model, cfg_level) if cfg_level else model

@@ -133,3 +133,47 @@ def test_long_chain_bf16_stays_close_to_fp32():
         plan.prepare(inp["hub"], inp["style"], L=L)
         outs[dt] = plan.sample_ddim(inp["x"].to(DEV), 50).cpu()
     assert mad(outs[F32], outs[BF16]) < 0.15
+
+
+def test_biwi_build_defined_semantics_vs_oracle():
+    """BIWI denoiser (models/fdm.py is unrunnable as shipped): build-defined 'Dec' struct with the
+    latent regrouped x8, style Mish, plain-Linear latent encoder, period-25 ALiBi.  Parity is pinned against the
+    oracle restatement only (NOT against the reference)."""
+    preset = "biwi"
+    w = W.make_fdm_weights(preset)
+    plan = DenoiserPlan(preset, w, F32, DEV)
+    B, L, t = 2, 33, 412
+    inp = W.synth_inputs(preset, B, L, seed=8)
+    hub = torch.randn(B, 2 * L, 768, generator=torch.Generator().manual_seed(3))      # wav2vec2-base features
+    plan.prepare(hub, inp["style"], L=L)
+    out = plan.denoise(inp["x"].to(DEV), t).cpu()
+    # oracle: pair the 768-wide frames -> 1536
+    ref = []
+    for b in range(B):
+        a = hub[b].reshape(L, 1536)
+        AFw = dict(w)
+        ref.append(_biwi_oracle_clip(AFw, a, t, inp["x"][b], inp["style"][b]))
+    assert mad(out, torch.stack(ref)) < TOL32
+
+
+def _biwi_oracle_clip(w, a_paired, t, x, style):
+    """Oracle forward for BIWI on already-paired audio rows [L, 1536]."""
+    import torch.nn.functional as Fn
+    p = W.PRESETS["biwi"]
+    AF = Fn.linear(FO.mish(Fn.linear(a_paired, w["audio_extract.0.weight"], w["audio_extract.0.bias"])),
+                   w["audio_extract.2.weight"], w["audio_extract.2.bias"])
+    L = x.shape[0] // p["G"]
+    h = Fn.linear(x.reshape(L, p["G"] * p["c"]), w["latent_encoder.0.weight"], w["latent_encoder.0.bias"])
+    tau = FO.mish(w["time_embedd.0.weight"][:, t] + w["time_embedd.0.bias"])
+    h = h + FO.mish(Fn.linear(style, w["style_embedd.weight"], w["style_embedd.bias"]))
+    h = h + FO.positional_table(p["d"], "sinus", 25, L)
+    mem = AF + tau
+    mask = FO.biased_mask(p["n_head"], L, 25)
+    d = p["d"]
+    for l in range(p["n_layers"]):
+        pre = f"transformer_decoder.layers.{l}."
+        h = Fn.layer_norm(h + FO._mha_self(h, w, pre + "self_attn.", p["n_head"], mask), (d,), w[pre + "norm1.weight"], w[pre + "norm1.bias"], 1e-5)
+        h = Fn.layer_norm(h + FO._mha_cross(h, mem, w, pre + "multihead_attn.", p["n_head"], True), (d,), w[pre + "norm2.weight"], w[pre + "norm2.bias"], 1e-5)
+        f = Fn.linear(torch.relu(Fn.linear(h, w[pre + "linear1.weight"], w[pre + "linear1.bias"])), w[pre + "linear2.weight"], w[pre + "linear2.bias"])
+        h = Fn.layer_norm(h + f, (d,), w[pre + "norm3.weight"], w[pre + "norm3.bias"], 1e-5)
+    return Fn.linear(h, w["latent_decoder.weight"], w["latent_decoder.bias"]).reshape(L * p["G"], p["c"])
