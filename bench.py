@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=0, help="profiling only: shorten the diffusion chain to this many steps")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -123,13 +124,16 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+        backend = os.environ.get("FDM_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for 1-GPU dry runs
+        kw = {"device_id": torch.device(dev)} if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     from fdm_amd import presets
     from fdm_amd._lib import BF16, F32
@@ -138,6 +142,8 @@ def main():
     from fdm_amd import synth as W
 
     preset, B, L, T, sampler, cfg = CONFIGS[a.config]
+    if a.profile_steps:
+        T = a.profile_steps
     p = presets.get(preset)
     dt = BF16 if a.dtype == "bf16" else F32
     plan = DenoiserPlan(preset, W.make_fdm_weights(preset), dt, dev)
@@ -191,7 +197,7 @@ def main():
     el = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
     if dist is not None:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        tt = torch.tensor([el], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt[0])
     assert torch.isfinite(out).all()

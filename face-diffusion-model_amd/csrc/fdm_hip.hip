@@ -367,4 +367,46 @@ int fdm_prog_replay(fdm_prog* p, int n, void* stream) {
   return FDM_OK;
 }
 
+// Experiment / fallback: run every lane's ops eagerly n times, each lane on its own stream fed by its own
+// host thread (no hipGraph).  Lanes are joined into `stream` at the end.
+int fdm_prog_run_lanes(fdm_prog* p, int n, void* stream) {
+  if (!p) return fail(FDM_ERR_ARG, "prog_run_lanes: null program");
+  if (g_rec) return fail(FDM_ERR_STATE, "prog_run_lanes: a program is still recording");
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e;
+  if (p->lane_streams.empty()) {
+    if ((e = hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+    for (int i = 0; i < p->n_lanes; ++i) {
+      hipStream_t st; hipEvent_t ev;
+      if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
+      p->lane_streams.push_back(st);
+      p->lane_events.push_back(ev);
+    }
+  }
+  if ((e = hipEventRecord(p->fork_event, s)) != hipSuccess) return hip_fail(e, "hipEventRecord");
+  for (auto st : p->lane_streams)
+    if ((e = hipStreamWaitEvent(st, p->fork_event, 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::vector<hipError_t> errs(p->n_lanes, hipSuccess);
+  std::vector<std::thread> th;
+  for (int ln = 0; ln < p->n_lanes; ++ln)
+    th.emplace_back([p, ln, n, dev, &errs] {
+      hipError_t er = hipSetDevice(dev);
+      for (int it = 0; er == hipSuccess && it < n; ++it)
+        for (size_t i = 0; er == hipSuccess && i < p->ops.size(); ++i)
+          if (p->lane[i] == ln) er = p->ops[i](p->lane_streams[ln]);
+      errs[ln] = er;
+    });
+  for (auto& t : th) t.join();
+  for (auto er : errs)
+    if (er != hipSuccess) return hip_fail(er, "prog_run_lanes");
+  for (int ln = 0; ln < p->n_lanes; ++ln) {
+    if ((e = hipEventRecord(p->lane_events[ln], p->lane_streams[ln])) != hipSuccess) return hip_fail(e, "hipEventRecord");
+    if ((e = hipStreamWaitEvent(s, p->lane_events[ln], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+  }
+  return FDM_OK;
+}
+
 }  // extern "C"

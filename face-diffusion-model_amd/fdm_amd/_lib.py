@@ -72,6 +72,7 @@ SYMBOLS = {
     "fdm_prog_replay": (ci, [vp, ci, vp]),
     "fdm_prog_num_ops": (ci, [vp]),
     "fdm_prog_set_lane": (ci, [vp, ci]),
+    "fdm_prog_run_lanes": (ci, [vp, ci, vp]),
 }
 
 _lib = None

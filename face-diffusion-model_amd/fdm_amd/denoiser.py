@@ -280,7 +280,9 @@ class DenoiserPlan:
             ops.cast(self.ws["x"], self.ws["xt"])
 
     def _run(self, prog, n_steps, use_graph):
-        if use_graph:
+        if use_graph and os.environ.get("FDM_EAGER_LANES") == "1":
+            prog.run_lanes(n_steps)
+        elif use_graph:
             prog.instantiate()
             prog.replay(n_steps)
         else:

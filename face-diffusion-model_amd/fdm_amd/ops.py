@@ -170,6 +170,9 @@ class Program:
     def instantiate(self):
         check(lib().fdm_prog_instantiate(self.h, stream()))
 
+    def run_lanes(self, n=1):
+        check(lib().fdm_prog_run_lanes(self.h, n, stream()))
+
     def replay(self, n=1):
         check(lib().fdm_prog_replay(self.h, n, stream()))
 

@@ -24,6 +24,8 @@ def gather_clips(local, dist=None, sizes=None):
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world = dist.get_world_size()
+    if dist.get_backend() != "nccl" and local.is_cuda:      # gloo dry runs: stage through host memory
+        return gather_clips(local.cpu(), dist, sizes).to(local.device)
     if sizes is None:
         n = torch.tensor([local.shape[0]], device=local.device, dtype=torch.int64)
         alln = [torch.zeros_like(n) for _ in range(world)]

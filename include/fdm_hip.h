@@ -184,6 +184,9 @@ int fdm_prog_num_ops(fdm_prog* p);
  * joined into the caller's stream once per replay call), so the chains' kernels overlap on the
  * device.  fdm_prog_run executes all ops in program order on the caller's stream. */
 int fdm_prog_set_lane(fdm_prog* p, int lane);
+/* Run every lane's ops eagerly n times (no hipGraph), each lane on its own internal stream fed by its own
+ * host thread; joined into `stream` at the end. */
+int fdm_prog_run_lanes(fdm_prog* p, int n, void* stream);
 
 #ifdef __cplusplus
 }

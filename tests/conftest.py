@@ -23,3 +23,14 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_library():
+    """The HIP library is built in-tree (git-ignored); build it if this checkout does not have it yet."""
+    from fdm_amd import _lib
+    so = os.path.join(ROOT, "oracle", "_build", "liboracle_c.so")
+    if not os.path.exists(_lib.LIB_PATH) or not os.path.exists(so):
+        import __graft_entry__ as g
+        g.build()
+    yield
