@@ -107,6 +107,7 @@ static hipError_t ln_launch_t(const fdm_ln_args& a, hipStream_t s) {
   switch (a.d) {
     case 256: hipLaunchKernelGGL((ln_kernel<T, 1>), grid, block, 0, s, a); break;
     case 512: hipLaunchKernelGGL((ln_kernel<T, 2>), grid, block, 0, s, a); break;
+    case 768: hipLaunchKernelGGL((ln_kernel<T, 3>), grid, block, 0, s, a); break;
     case 1024: hipLaunchKernelGGL((ln_kernel<T, 4>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, const floa
   const int oa = threadIdx.x, ob = threadIdx.x + 256;
 #pragma unroll
   for (int k = 0; k < 10; ++k) { wa[k] = w[oa * 10 + k]; wb[k] = w[ob * 10 + k]; }
-  const float ba = bias[oa], bb = bias[ob];
+  const float ba = bias ? bias[oa] : 0.f, bb = bias ? bias[ob] : 0.f;
   for (int tt = 0; tt < TT; ++tt) {
     const int t = t0 + tt;
     if (t >= T0) break;
@@ -359,6 +360,44 @@ __global__ __launch_bounds__(256) void leaky_instnorm_kernel(const float* x, flo
   for (int l = 0; l < L; ++l) {
     const float v = (act_apply(xp[(size_t)l * d], ACT_LEAKY02) - mean) * rstd;
     const size_t o = ((size_t)b * L + l) * d + ch;
+    if (y_f32) y_f32[o] = v;
+    if (y_t) y_t[o] = from_f32<T>(v);
+  }
+}
+
+// GroupNorm(num_groups = C) of wav2vec2's first conv layer: per (clip, channel) statistics over time
+// (biased variance), affine, then activation.  Workgroup = 16 time-lanes x 64 channels; the time-lanes
+// stride over t and combine through LDS; three passes (mean, centred variance, normalise).
+template <typename T>
+__global__ __launch_bounds__(1024) void time_groupnorm_kernel(const float* x, const float* gamma, const float* beta, float* y_f32, T* y_t,
+                                                              int Tn, int C, float eps, int act) {
+  __shared__ float red[16][64];
+  const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + cl, b = blockIdx.y;
+  const bool ok = ch < C;
+  const float* xp = x + (size_t)b * Tn * C + (ok ? ch : 0);
+  float s = 0.f;
+  if (ok) for (int t = tl; t < Tn; t += 16) s += xp[(size_t)t * C];
+  red[tl][cl] = s;
+  __syncthreads();
+  float mean = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mean += red[i][cl];
+  mean /= Tn;
+  __syncthreads();
+  float q = 0.f;
+  if (ok) for (int t = tl; t < Tn; t += 16) { const float c = xp[(size_t)t * C] - mean; q += c * c; }
+  red[tl][cl] = q;
+  __syncthreads();
+  float var = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) var += red[i][cl];
+  const float rstd = 1.f / sqrtf(var / Tn + eps);
+  if (!ok) return;
+  const float gm = gamma ? gamma[ch] : 1.f, bt = beta ? beta[ch] : 0.f;
+  for (int t = tl; t < Tn; t += 16) {
+    const float v = act_apply((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
+    const size_t o = ((size_t)b * Tn + t) * C + ch;
     if (y_f32) y_f32[o] = v;
     if (y_t) y_t[o] = from_f32<T>(v);
   }

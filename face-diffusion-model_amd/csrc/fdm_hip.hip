@@ -119,7 +119,7 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream) {
 
 int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
   if (!a || !a->x || !a->gamma || !a->beta) return fail(FDM_ERR_ARG, "layernorm: null operand");
-  if (a->d != 256 && a->d != 512 && a->d != 1024) return fail(FDM_ERR_SHAPE, "layernorm: d=%d unsupported (256, 512, 1024)", a->d);
+  if (a->d != 256 && a->d != 512 && a->d != 768 && a->d != 1024) return fail(FDM_ERR_SHAPE, "layernorm: d=%d unsupported (256, 512, 768, 1024)", a->d);
   if (a->M <= 0) return fail(FDM_ERR_SHAPE, "layernorm: M must be positive");
   if (!a->y_f32 && !a->y_t) return fail(FDM_ERR_ARG, "layernorm: no output");
   fdm_ln_args c = *a;
@@ -196,7 +196,7 @@ int fdm_op_group_pad(const void* in, void* out, int B, int T, int d, int groups,
 }
 
 int fdm_op_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int n, int T0, void* stream) {
-  if (!wav || !w || !bias || !out || B <= 0 || n < 10 || T0 != (n - 10) / 5 + 1) return fail(FDM_ERR_SHAPE, "conv0: bad shape (n=%d, T0=%d)", n, T0);
+  if (!wav || !w || !out || B <= 0 || n < 10 || T0 != (n - 10) / 5 + 1) return fail(FDM_ERR_SHAPE, "conv0: bad shape (n=%d, T0=%d)", n, T0);
   return submit([=](hipStream_t s) {
     hipLaunchKernelGGL(fdm::conv0_kernel, dim3((T0 + 15) / 16, B), dim3(256), 0, s, wav, w, bias, out, n, T0);
     return hipGetLastError();
@@ -211,6 +211,17 @@ int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L,
     else hipLaunchKernelGGL((fdm::leaky_instnorm_kernel<float>), grid, dim3(256), 0, s, x, y_f32, (float*)y_t, L, d, eps);
     return hipGetLastError();
   }, stream, "leaky_instnorm");
+}
+
+int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, int B, int T, int C,
+                          float eps, int act, int dtype, void* stream) {
+  if (!x || (!y_f32 && !y_t) || B <= 0 || T <= 0 || C <= 0) return fail(FDM_ERR_ARG, "time_groupnorm: bad argument");
+  return submit([=](hipStream_t s) {
+    dim3 grid((C + 63) / 64, B);
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::time_groupnorm_kernel<fdm::bf16>), grid, dim3(1024), 0, s, x, gamma, beta, y_f32, (fdm::bf16*)y_t, T, C, eps, act);
+    else hipLaunchKernelGGL((fdm::time_groupnorm_kernel<float>), grid, dim3(1024), 0, s, x, gamma, beta, y_f32, (float*)y_t, T, C, eps, act);
+    return hipGetLastError();
+  }, stream, "time_groupnorm");
 }
 
 int fdm_op_adain(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps, void* stream) {

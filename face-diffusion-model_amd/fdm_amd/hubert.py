@@ -20,6 +20,8 @@ Kernel mapping (all through the C ABI):
                                                GELU -> FFN2 GEMM + residual
   final LayerNorm                              fdm_op_layernorm
 """
+from dataclasses import dataclass
+
 import torch
 
 from . import ops
@@ -27,8 +29,27 @@ from ._lib import ACT_GELU_ERF, ACT_NONE, BF16, F32, FdmError
 
 CONV_KERNEL = (10, 3, 3, 3, 3, 2, 2)
 CONV_STRIDE = (5, 2, 2, 2, 2, 2, 2)
-N_HEAD, HD, D, CD, FFN = 16, 64, 1024, 512, 4096
+CD = 512
 POS_K, POS_G = 128, 16
+
+
+@dataclass(frozen=True)
+class AudioEncoderConfig:
+    """The two audio encoders of the reference share one op graph up to these switches."""
+    name: str
+    D: int            # hidden size
+    H: int            # attention heads (head_dim 64 for both)
+    FFN: int
+    n_layers: int
+    conv_norm: str    # 'layer': LayerNorm(512) after every conv (HuBERT-large) | 'group': GroupNorm on conv 0 only
+    conv_bias: bool
+    stable_ln: bool   # True: pre-LN layers + final LayerNorm | False: LayerNorm before the stack, post-LN layers
+
+
+HUBERT_LARGE = AudioEncoderConfig("hubert-large", 1024, 16, 4096, 24, "layer", True, True)
+# models/wav2vec.py:69-143 over transformers Wav2Vec2Model ('wav2vec2-base-960h' config): the BIWI audio encoder
+WAV2VEC2_BASE = AudioEncoderConfig("wav2vec2-base", 768, 12, 3072, 12, "group", False, False)
+N_HEAD, HD, D, FFN = 16, 64, 1024, 4096          # HuBERT-large constants (kept for callers)
 
 
 def conv_lengths(n):
@@ -56,7 +77,10 @@ def _get(w, name):
 
 
 class HubertPlan:
-    def __init__(self, weights, n_layers=24, dtype=F32, device="cuda:0", prefix=""):
+    def __init__(self, weights, n_layers=None, dtype=F32, device="cuda:0", prefix="", cfg=HUBERT_LARGE):
+        self.cfg = cfg
+        n_layers = cfg.n_layers if n_layers is None else n_layers
+        D = cfg.D
         self.dtype, self.td = dtype, ops.tdtype(dtype)
         self.device = dv = torch.device(device)
         self.n_layers = n_layers
@@ -72,7 +96,10 @@ class HubertPlan:
                     wk = wt.reshape(CD, k).contiguous()                       # fp32, direct kernel
                 else:
                     wk = op(wt.permute(0, 2, 1).reshape(CD, k * CD))          # [out, (k, in)]
-                self.conv.append((wk, g(p + "conv.bias"), g(p + "layer_norm.weight"), g(p + "layer_norm.bias")))
+                has_norm = cfg.conv_norm == "layer" or i == 0
+                self.conv.append((wk, g(p + "conv.bias") if cfg.conv_bias else None,
+                                  g(p + "layer_norm.weight") if has_norm else None,
+                                  g(p + "layer_norm.bias") if has_norm else None))
             self.fp_ln = (g("feature_projection.layer_norm.weight"), g("feature_projection.layer_norm.bias"))
             self.fp_w, self.fp_b = op(g("feature_projection.projection.weight")), g("feature_projection.projection.bias")
             # weight-normalised grouped positional conv (weight_norm dim = 2), repacked per group
@@ -97,8 +124,9 @@ class HubertPlan:
         self.stream.synchronize()
 
     def forward(self, wav):
-        """wav [B, n] fp32 (processor-normalised) -> last_hidden_state [B, N, 1024] fp32."""
-        dv, td, dt = self.device, self.td, self.dtype
+        """wav [B, n] fp32 (processor-normalised) -> last_hidden_state [B, N, D] fp32."""
+        dv, td, dt, cfg = self.device, self.td, self.dtype, self.cfg
+        D, N_HEAD, FFN = cfg.D, cfg.H, cfg.FFN
         if wav.dim() == 1:
             wav = wav.unsqueeze(0)
         wav = wav.detach().to(device=dv, dtype=torch.float32).contiguous()
@@ -115,20 +143,34 @@ class HubertPlan:
             x32 = z(B * Ts[0], CD)
             ops.conv0(wav, self.conv[0][0], self.conv[0][1], x32, B, n, Ts[0])
             xt = z(B * Ts[0], CD, dtp=td)
-            ops.layernorm(x32, self.conv[0][2], self.conv[0][3], B * Ts[0], CD, act=ACT_GELU_ERF, y_t=xt, dtype=dt)
+            if cfg.conv_norm == "layer":
+                ops.layernorm(x32, self.conv[0][2], self.conv[0][3], B * Ts[0], CD, act=ACT_GELU_ERF, y_t=xt, dtype=dt)
+            else:   # GroupNorm(512 groups) over time, affine, then GELU (Wav2Vec2GroupNormConvLayer)
+                ops.time_groupnorm(x32, self.conv[0][2], self.conv[0][3], B, Ts[0], CD, y_t=xt, act=ACT_GELU_ERF, dtype=dt)
             Tin = Ts[0]
             g6 = None
             for i in range(1, 7):
                 k, s, To = CONV_KERNEL[i], CONV_STRIDE[i], Ts[i]
-                y32 = z(B * To, CD)
-                ops.gemm(xt, self.conv[i][0], To, CD, k * CD, lda=s * CD, bias=self.conv[i][1], out_f32=y32,
-                         batch=B, a_bs=Tin * CD, out_bs=To * CD)
-                if i < 6:
-                    xt = z(B * To, CD, dtp=td)
-                    ops.layernorm(y32, self.conv[i][2], self.conv[i][3], B * To, CD, act=ACT_GELU_ERF, y_t=xt, dtype=dt)
-                else:
-                    g6 = z(B * To, CD)
-                    ops.layernorm(y32, self.conv[i][2], self.conv[i][3], B * To, CD, act=ACT_GELU_ERF, y_f32=g6)
+                if cfg.conv_norm == "layer":
+                    y32 = z(B * To, CD)
+                    ops.gemm(xt, self.conv[i][0], To, CD, k * CD, lda=s * CD, bias=self.conv[i][1], out_f32=y32,
+                             batch=B, a_bs=Tin * CD, out_bs=To * CD)
+                    if i < 6:
+                        xt = z(B * To, CD, dtp=td)
+                        ops.layernorm(y32, self.conv[i][2], self.conv[i][3], B * To, CD, act=ACT_GELU_ERF, y_t=xt, dtype=dt)
+                    else:
+                        g6 = z(B * To, CD)
+                        ops.layernorm(y32, self.conv[i][2], self.conv[i][3], B * To, CD, act=ACT_GELU_ERF, y_f32=g6)
+                else:   # conv (no norm) + GELU fused in the GEMM epilogue
+                    if i < 6:
+                        nx = z(B * To, CD, dtp=td)
+                        ops.gemm(xt, self.conv[i][0], To, CD, k * CD, lda=s * CD, bias=self.conv[i][1], act=ACT_GELU_ERF,
+                                 out_t=nx, batch=B, a_bs=Tin * CD, out_bs=To * CD)
+                        xt = nx
+                    else:
+                        g6 = z(B * To, CD)
+                        ops.gemm(xt, self.conv[i][0], To, CD, k * CD, lda=s * CD, bias=self.conv[i][1], act=ACT_GELU_ERF,
+                                 out_f32=g6, batch=B, a_bs=Tin * CD, out_bs=To * CD)
                 Tin = To
             # --- even crop (models/hubert.py:95-96) + feature projection ---
             T6 = Ts[6]
@@ -149,7 +191,7 @@ class HubertPlan:
                          w_bs=dg * POS_K * dg, bias=self.pc_b, bias_bs=dg, act=ACT_GELU_ERF, resid=h[b * N:], ldr=D,
                          out_f32=h2[b * N:], ldo_f32=D, out_bs=dg)
             h = h2
-            # --- encoder layers (pre-LN) ---
+            # --- encoder layers ---
             Lpad = (N + 31) // 32 * 32
             xt = z(M, D, dtp=td)
             qkv = z(M, 3 * D, dtp=td)
@@ -157,17 +199,35 @@ class HubertPlan:
             ctx = z(M, D, dtp=td)
             u = z(M, FFN, dtp=td)
             hb = z(M, D)
-            for ly in self.layers:
-                ops.layernorm(h, ly["ln1"][0], ly["ln1"][1], M, D, y_t=xt, dtype=dt)
-                ops.gemm(xt, ly["wqkv"], M, 3 * D, D, bias=ly["bqkv"], out_t=qkv, ldo_t=3 * D, out_vt=vt, vt_col0=2 * D,
-                         vt_L=N, vt_Lpad=Lpad, vt_hd=HD)
-                ops.attention(qkv, qkv[:, D:], vt, ctx, B=B, H=N_HEAD, L=N, hd=HD, ldq=3 * D, ldk=3 * D, ldo=D, Lpad=Lpad,
-                              scale=HD ** -0.5, causal=False)
-                ops.gemm(ctx, ly["wo"], M, D, D, bias=ly["bo"], resid=h, out_f32=hb)
-                ops.layernorm(hb, ly["ln2"][0], ly["ln2"][1], M, D, y_t=xt, dtype=dt)
-                ops.gemm(xt, ly["w1"], M, FFN, D, bias=ly["b1"], act=ACT_GELU_ERF, out_t=u)
-                ops.gemm(u, ly["w2"], M, D, FFN, bias=ly["b2"], resid=hb, out_f32=h)
-            out = z(M, D)
-            ops.layernorm(h, self.final_ln[0], self.final_ln[1], M, D, y_f32=out)
+            if cfg.stable_ln:      # pre-LN layers, final LayerNorm (HubertEncoderStableLayerNorm)
+                for ly in self.layers:
+                    ops.layernorm(h, ly["ln1"][0], ly["ln1"][1], M, D, y_t=xt, dtype=dt)
+                    ops.gemm(xt, ly["wqkv"], M, 3 * D, D, bias=ly["bqkv"], out_t=qkv, ldo_t=3 * D, out_vt=vt, vt_col0=2 * D,
+                             vt_L=N, vt_Lpad=Lpad, vt_hd=HD)
+                    ops.attention(qkv, qkv[:, D:], vt, ctx, B=B, H=N_HEAD, L=N, hd=HD, ldq=3 * D, ldk=3 * D, ldo=D, Lpad=Lpad,
+                                  scale=HD ** -0.5, causal=False)
+                    ops.gemm(ctx, ly["wo"], M, D, D, bias=ly["bo"], resid=h, out_f32=hb)
+                    ops.layernorm(hb, ly["ln2"][0], ly["ln2"][1], M, D, y_t=xt, dtype=dt)
+                    ops.gemm(xt, ly["w1"], M, FFN, D, bias=ly["b1"], act=ACT_GELU_ERF, out_t=u)
+                    ops.gemm(u, ly["w2"], M, D, FFN, bias=ly["b2"], resid=hb, out_f32=h)
+                out = z(M, D)
+                ops.layernorm(h, self.final_ln[0], self.final_ln[1], M, D, y_f32=out)
+            else:                  # LayerNorm before the stack, post-LN layers (Wav2Vec2Encoder / Wav2Vec2EncoderLayer)
+                x1 = z(M, D)
+                both = dt == BF16
+                ht = xt if both else None
+                ops.layernorm(h, self.final_ln[0], self.final_ln[1], M, D, y_f32=hb, y_t=ht, dtype=dt)
+                for ly in self.layers:
+                    a_in = xt if both else hb
+                    ops.gemm(a_in, ly["wqkv"], M, 3 * D, D, bias=ly["bqkv"], out_t=qkv, ldo_t=3 * D, out_vt=vt, vt_col0=2 * D,
+                             vt_L=N, vt_Lpad=Lpad, vt_hd=HD)
+                    ops.attention(qkv, qkv[:, D:], vt, ctx, B=B, H=N_HEAD, L=N, hd=HD, ldq=3 * D, ldk=3 * D, ldo=D, Lpad=Lpad,
+                                  scale=HD ** -0.5, causal=False)
+                    ops.gemm(ctx, ly["wo"], M, D, D, bias=ly["bo"], resid=hb, out_f32=x1)
+                    ops.layernorm(x1, ly["ln1"][0], ly["ln1"][1], M, D, y_f32=hb, y_t=ht, dtype=dt)
+                    ops.gemm(a_in, ly["w1"], M, FFN, D, bias=ly["b1"], act=ACT_GELU_ERF, out_t=u)
+                    ops.gemm(u, ly["w2"], M, D, FFN, bias=ly["b2"], resid=hb, out_f32=x1)
+                    ops.layernorm(x1, ly["ln2"][0], ly["ln2"][1], M, D, y_f32=hb, y_t=ht, dtype=dt)
+                out = hb
         cur.wait_stream(self.stream)
         return out.view(B, N, D)

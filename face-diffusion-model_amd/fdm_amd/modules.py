@@ -26,7 +26,7 @@ import torch.nn as nn
 from . import presets, schedule, synth
 from ._lib import BF16, F32, FdmError
 from .denoiser import DenoiserPlan
-from .hubert import HubertPlan, num_frames
+from .hubert import HUBERT_LARGE, WAV2VEC2_BASE, HubertPlan, num_frames
 from .vq import VQPlan
 
 
@@ -111,6 +111,28 @@ class HubertModel(ParamTree):
         return SimpleNamespace(last_hidden_state=out, hidden_states=None, attentions=None)
 
 
+class Wav2Vec2Model(HubertModel):
+    """wav2vec2-base (12 layers, d = 768) with the reference's forward override (models/wav2vec.py:69-143):
+    the BIWI denoiser's audio encoder.  Same HF key names; GroupNorm conv stack, post-LN encoder."""
+
+    def __init__(self, config=None, n_layers=12, seed=0, dtype=None):
+        ParamTree.__init__(self)
+        self.n_layers = int(getattr(config, "num_hidden_layers", n_layers)) if config is not None else n_layers
+        self.config = config or SimpleNamespace(num_hidden_layers=self.n_layers, hidden_size=768, output_attentions=False)
+        for k, v in synth.make_wav2vec_weights(self.n_layers, seed).items():
+            self._register(k, v)
+        self.feature_extractor._freeze_parameters = lambda: None
+        self._dtype = compute_dtype(dtype)
+        self._plan = None
+        self._plan_stale = True
+
+    def _get_plan(self, device):
+        if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
+            self._plan = HubertPlan(self.state_dict(), self.n_layers, self._dtype, device, cfg=WAV2VEC2_BASE)
+            self._plan_stale = False
+        return self._plan
+
+
 # --------------------------------------------------------------------------------------------------
 class _FDMBase(ParamTree):
     preset_name = "vocaset"
@@ -130,7 +152,8 @@ class _FDMBase(ParamTree):
         self.latent_decoder.bias.data.zero_()
         n_pe = 630 if self.preset.pe == "periodic" else 5000
         self._register("PE.pe", schedule.positional_table(feature_dim, self.preset.pe, self.preset.period, n_pe).unsqueeze(0), buffer=True)
-        self.audio_encoder = HubertModel.from_pretrained("/data/WX/hubert-large-ls960-ft") if audio_encoder else None
+        enc_cls = Wav2Vec2Model if self.preset_name == "biwi" else HubertModel     # models/fdm.py:19 vs models/fdm_vocaset.py:17
+        self.audio_encoder = enc_cls.from_pretrained("/data/WX/hubert-large-ls960-ft") if audio_encoder else None
         self.one_hot_timesteps = None
         self._dtype = compute_dtype(dtype)
         self._plan = None
@@ -220,10 +243,11 @@ class FDMMead(_FDMBase):
 
 
 class FDMBiwi(_FDMBase):
-    """BIWI denoiser (build-defined semantics: 'Dec' struct, latent regrouped x8; parity unpinned vs reference)."""
+    """BIWI denoiser (build-defined semantics: 'Dec' struct, latent regrouped x8; parity unpinned vs reference);
+    audio encoder = wav2vec2-base (pinned against the reference, tests/golden/wav2vec.npz)."""
     preset_name = "biwi"
 
-    def __init__(self, feature_dim=1024, vertice_dim=70110, n_head=4, num_layers=8, struct="Dec", dtype=None, audio_encoder=False):
+    def __init__(self, feature_dim=1024, vertice_dim=70110, n_head=4, num_layers=8, struct="Dec", dtype=None, audio_encoder=True):
         super().__init__()
         self._build(feature_dim, n_head, num_layers, struct, dtype, audio_encoder)
 

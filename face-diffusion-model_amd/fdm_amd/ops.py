@@ -126,6 +126,10 @@ def leaky_instnorm(x, B, L, d, *, y_f32=None, y_t=None, eps=1e-5, dtype=F32):
     check(lib().fdm_op_leaky_instnorm(_p(x), _p(y_f32), _p(y_t), B, L, d, eps, dtype, stream()))
 
 
+def time_groupnorm(x, gamma, beta, B, T, C, *, y_f32=None, y_t=None, eps=1e-5, act=ACT_NONE, dtype=F32):
+    check(lib().fdm_op_time_groupnorm(_p(x), _p(gamma), _p(beta), _p(y_f32), _p(y_t), B, T, C, eps, act, dtype, stream()))
+
+
 def adain(content, style, out, NC, Lc, Ls, eps=1e-5):
     check(lib().fdm_op_adain(_p(content), _p(style), _p(out), NC, Lc, Ls, eps, stream()))
 

@@ -91,6 +91,18 @@ def hubert_shapes(n_layers=24, hidden=1024, ffn=4096, conv_dim=512):
     return s
 
 
+def wav2vec_shapes(n_layers=12, hidden=768, ffn=3072, conv_dim=512):
+    """transformers Wav2Vec2Model (base: feat_extract_norm='group', no conv bias, post-LN encoder) parameter names."""
+    s = hubert_shapes(n_layers, hidden, ffn, conv_dim)
+    for i in range(7):
+        pre = f"feature_extractor.conv_layers.{i}."
+        del s[pre + "conv.bias"]
+        if i > 0:
+            del s[pre + "layer_norm.weight"]
+            del s[pre + "layer_norm.bias"]
+    return s
+
+
 def vq_shapes(preset, hidden=VQ_HIDDEN, n_layers=VQ_LAYERS, ffn=VQ_FFN):
     """Quantizer + decoder parameters (encoder.* is training-only, out of scope)."""
     p = _pd(preset)
@@ -159,6 +171,10 @@ def make_fdm_weights(preset, seed=0):
 
 def make_hubert_weights(n_layers=24, seed=0, prefix=""):
     return make_weights(hubert_shapes(n_layers), seed, prefix)
+
+
+def make_wav2vec_weights(n_layers=12, seed=0, prefix=""):
+    return make_weights(wav2vec_shapes(n_layers), seed, prefix)
 
 
 def make_vq_weights(preset, seed=0):

@@ -92,7 +92,7 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream);
  * (nn.LayerNorm eps 1e-5: decoder norm1-3 models/fdm_vocaset.py:45; HuBERT; VQ Norm
  * models/lib/base_models.py:37-52).  add_tab row index = tab_index[*tab_step] if tab_step else
  * tab_index[0] (device ints) -- this is how the folded cross-attention time term enters
- * (SURVEY.md a11x).  d in {256, 512, 1024}.                                                  */
+ * (SURVEY.md a11x).  d in {256, 512, 768, 1024}.                                                  */
 typedef struct fdm_ln_args {
   const float* x; int M, d;
   const float* add_mat;               /* [M, d] or NULL */
@@ -151,10 +151,14 @@ int fdm_op_small_linear(const float* x, const float* W, const float* bias, float
                         int act, void* stream);
 /* out[b, k, :] = in[b, clamp(k - pad, 0, L-1), :] for k in [0, L + 2*pad): replicate padding, channels-last */
 int fdm_op_pad_rows(const void* in, void* out, int B, int L, int d, int pad, int dtype, int zero, void* stream);
-/* HuBERT conv layer 0: wav [B, n] -> out [B, T0, 512], Conv1d(1, 512, k=10, s=5) + bias */
+/* HuBERT / wav2vec2 conv layer 0: wav [B, n] -> out [B, T0, 512], Conv1d(1, 512, k=10, s=5) (+ bias if non-NULL) */
 int fdm_op_conv0(const float* wav, const float* w, const float* bias, float* out, int B, int n, int T0, void* stream);
 /* per-(clip, channel) InstanceNorm1d over L after LeakyReLU(0.2): models/vq_vae_vocaset.py:204-209 */
 int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L, int d, float eps, int dtype, void* stream);
+/* GroupNorm(num_groups = C, affine) over time + activation, channels-last x [B, T, C]: first conv layer of
+ * wav2vec2-base (transformers Wav2Vec2GroupNormConvLayer; BIWI audio encoder, models/wav2vec.py:69-143) */
+int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, int B, int T, int C,
+                          float eps, int act, int dtype, void* stream);
 /* AdaIN (utiles/adaIN.py:4-22): content, style [N, C, Lc], [N, C, Ls] -> out [N, C, Lc] */
 int fdm_op_adain(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps, void* stream);
 /* regroup [B, T, d] -> [groups, B, T + 2*pad, d/groups] zero padded (HuBERT positional conv input) */

@@ -408,6 +408,35 @@ def g10_state_keys():
     print(f"  wrote state_keys.json ({os.path.getsize(path) / 1024:.0f} KiB)", {k: len(v) for k, v in out.items()})
 
 
+def g11_wav2vec():
+    """wav2vec2-base (BIWI audio encoder, models/wav2vec.py) with random-init base config."""
+    import models.wav2vec as rw
+    from transformers import Wav2Vec2Config
+    from oracle import wav2vec_oracle as WO
+    out = {}
+    for layers in (2, 12):
+        cfg = Wav2Vec2Config(num_hidden_layers=layers, attn_implementation="eager")
+        m = rw.Wav2Vec2Model(cfg).eval()
+        ww = W.make_wav2vec_weights(layers)
+        sd = m.state_dict()
+        missing = [k for k in sd if k not in ww]
+        assert not missing, missing
+        m.load_state_dict(ww, strict=True)
+        for secs, n in ((2, 32000), (10, 160000)):
+            if layers == 2 and secs == 10:
+                continue
+            g = torch.Generator().manual_seed(20 + secs)
+            wav = HO.processor_normalize(torch.randn(n, generator=g) * 0.1)
+            ref = m(wav.unsqueeze(0)).last_hidden_state[0]
+            ours = WO.wav2vec_forward_clip(ww, wav, layers)
+            print(f"  wav2vec2 L{layers} {secs}s: out {tuple(ref.shape)} |ref-oracle|={mad(ref, ours):.3e} |ref|max={float(ref.abs().max()):.2f}")
+            if secs == 2:
+                out[f"out_L{layers}_2s"] = ref.numpy()
+            else:
+                out[f"out_L{layers}_10s_rows8"] = ref[::8].numpy()
+    save("wav2vec", **out)
+
+
 ALL = {
     "schedule": g1_schedule, "masks": g2_masks,
     "fdm_step_vocaset": lambda: g3_fdm_step("vocaset"),
@@ -417,7 +446,7 @@ ALL = {
     "chains_vocaset": lambda: g4_chains("vocaset"),
     "chains_mead": lambda: g4_chains("mead"),
     "chains_vocaset_tiny": lambda: g4_chains("vocaset_tiny"),
-    "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio, "state_keys": g10_state_keys,
+    "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio, "state_keys": g10_state_keys, "wav2vec": g11_wav2vec,
 }
 
 if __name__ == "__main__":

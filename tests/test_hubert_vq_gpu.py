@@ -137,3 +137,21 @@ def test_vq_decode_batch_uses_pe0_for_every_clip_and_bf16():
     assert mad(out, ref) < 1e-4
     outb = vq_plan("vocaset", BF16).decode(zq.to(DEV))
     assert mad(outb, ref) < 0.5          # decoder outputs are O(12); bf16 operands
+
+
+def test_wav2vec2_base_vs_golden(golden):
+    """BIWI audio encoder on the HIP path (GroupNorm conv stack, post-LN encoder, d = 768)."""
+    from fdm_amd.hubert import WAV2VEC2_BASE
+    g = golden("wav2vec")
+
+    def wv(secs, n):
+        gg = torch.Generator().manual_seed(20 + secs)
+        return HO.processor_normalize(torch.randn(n, generator=gg) * 0.1)
+    p2 = HubertPlan(W.make_wav2vec_weights(2), 2, F32, DEV, cfg=WAV2VEC2_BASE)
+    assert mad(p2.forward(wv(2, 32000))[0], g["out_L2_2s"]) < 1e-4
+    p12 = HubertPlan(W.make_wav2vec_weights(12), 12, F32, DEV, cfg=WAV2VEC2_BASE)
+    o = p12.forward(torch.stack([wv(2, 32000), wv(3, 32000)]))
+    assert o.shape == (2, 98, 768) and mad(o[0], g["out_L12_2s"]) < 1e-4
+    assert mad(p12.forward(wv(10, 160000))[0, ::8], g["out_L12_10s_rows8"]) < 1e-4
+    pb = HubertPlan(W.make_wav2vec_weights(12), 12, BF16, DEV, cfg=WAV2VEC2_BASE)
+    assert mad(pb.forward(wv(2, 32000))[0], g["out_L12_2s"]) < 0.15

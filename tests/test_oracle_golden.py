@@ -152,3 +152,13 @@ def test_cfg1_e2e_hoisted_and_folded(golden):
     den = lambda x, t: FO.fdm_forward(wd, "vocaset", hub, t, x, sid, None, folded=True)
     out = FO.ddim_sample(den, xT.clone(), 50)
     assert mad(out, g["final"]) < TOL
+
+
+def test_wav2vec2_base(golden):
+    """BIWI audio encoder (models/wav2vec.py) -- SURVEY.md section 8f rank 2."""
+    from oracle import wav2vec_oracle as WO
+    g = golden("wav2vec")
+    gen = torch.Generator().manual_seed(22)
+    wav = HO.processor_normalize(torch.randn(32000, generator=gen) * 0.1)
+    assert mad(WO.wav2vec_forward_clip(W.make_wav2vec_weights(2), wav, 2), g["out_L2_2s"]) < TOL
+    assert mad(WO.wav2vec_forward_clip(W.make_wav2vec_weights(12), wav, 12), g["out_L12_2s"]) < TOL

@@ -129,3 +129,16 @@ def test_mead_end_to_end_animate_with_evq():
     verts = ae.decode(quanted)
     assert verts.shape == (2, L, 15069)
     assert mad(verts, VO.decode(wv, "mead", ozq)) < 1e-4
+
+
+def test_biwi_demo_end_to_end(tmp_path):
+    """demo_biwi.py wiring: wav -> wav2vec2-base -> pair frames -> BIWI denoiser (head_dim 256) -> DDIM -> quant
+    (256 x 128 codebook) -> decode to 70110 coordinates."""
+    from scipy.io import wavfile
+    from fdm_amd import pipeline
+    wav = (np.random.default_rng(1).standard_normal(16000) * 3000).astype(np.int16)
+    wp = str(tmp_path / "biwi.wav")
+    wavfile.write(wp, 16000, wav)
+    dst = pipeline.demo_main("biwi", ["--audio_file", wp, "--audio_path", str(tmp_path / "result"), "--ddim_steps", "3"])
+    arr = np.load(dst)
+    assert arr.shape == (1, 49, 70110) and np.isfinite(arr).all()

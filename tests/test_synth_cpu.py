@@ -23,5 +23,7 @@ def test_generators_agree():
         assert all(torch.equal(ia[k], ib[k]) for k in ia)
     a, b = synth.make_hubert_weights(1), W.make_hubert_weights(1)
     assert all(torch.equal(a[k], b[k]) for k in a) and a.keys() == b.keys()
+    a, b = synth.make_wav2vec_weights(1), W.make_wav2vec_weights(1)
+    assert all(torch.equal(a[k], b[k]) for k in a) and a.keys() == b.keys()
     a, b = synth.make_vq_weights("mead"), W.make_vq_weights("mead")
     assert all(torch.equal(a[k], b[k]) for k in a) and a.keys() == b.keys()
