@@ -403,6 +403,30 @@ __global__ __launch_bounds__(1024) void time_groupnorm_kernel(const float* x, co
   }
 }
 
+// sum |a - b|^p (p = 1, 2) in two deterministic stages: per-block partials, then one block folds them in
+// a fixed order (F.mse_loss / F.l1_loss of p_losses, diffusion_BIWI_encoder_decoder.py:744-749).
+__global__ __launch_bounds__(256) void diff_partial_kernel(const float* a, const float* b, float* partial, long long n, int l1) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    s += l1 ? fabsf(d) : d * d;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void diff_final_kernel(const float* partial, int nb, float scale, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * scale;
+}
+
 // AdaIN (utiles/adaIN.py:4-22): one wavefront per (n, c) row; unbiased variance + eps.
 __global__ __launch_bounds__(256) void adain_kernel(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps) {
   const int lane = threadIdx.x & 63;

@@ -224,6 +224,16 @@ int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta,
   }, stream, "time_groupnorm");
 }
 
+int fdm_op_mean_diff(const float* a, const float* b, float* partial, float* out, long long n, int l1, void* stream) {
+  if (!a || !b || !partial || !out || n <= 0) return fail(FDM_ERR_ARG, "mean_diff: bad argument");
+  return submit([=](hipStream_t s) {
+    const int nb = grid_for(n) > 1024 ? 1024 : grid_for(n);
+    hipLaunchKernelGGL(fdm::diff_partial_kernel, dim3(nb), dim3(256), 0, s, a, b, partial, n, l1);
+    hipLaunchKernelGGL(fdm::diff_final_kernel, dim3(1), dim3(256), 0, s, (const float*)partial, nb, 1.0f / (float)n, out);
+    return hipGetLastError();
+  }, stream, "mean_diff");
+}
+
 int fdm_op_adain(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps, void* stream) {
   if (!content || !style || !out || NC <= 0 || Lc < 2 || Ls < 2) return fail(FDM_ERR_ARG, "adain: bad argument");
   return submit([=](hipStream_t s) {

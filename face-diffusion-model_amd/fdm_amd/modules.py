@@ -308,9 +308,28 @@ class GaussianDiffusion(nn.Module):
             self._extract(self.posterior_log_variance_clipped, t, x_t.shape)
 
     def q_sample(self, x_start, t, noise=None):
+        """sqrt(abar_t) x0 + sqrt(1 - abar_t) eps (:729-735) through the fused scheduler kernel (all clips share t)."""
         noise = torch.randn_like(x_start) if noise is None else noise
-        return self._extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start + \
-            self._extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise
+        if not x_start.is_cuda:
+            return self._extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start + \
+                self._extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise
+        from . import ops
+        x0 = x_start.float().contiguous()
+        z = noise.float().contiguous()
+        out = torch.empty_like(x0)
+        zero = torch.zeros(self.num_timesteps, device=x0.device)
+        tt = t.flatten()[:1].to(torch.int32).contiguous()
+        ops.sched_step(0, x0, z, out, x0.numel(), tseq=tt, c1=self.sqrt_alphas_cumprod, c2=self.sqrt_one_minus_alphas_cumprod,
+                       sigma=zero, noise=z)
+        return out
+
+    def p_losses(self, x_start, t, audio, *cond, noise=None):
+        """Forward value of the training loss (:737-755): q_sample -> denoiser -> mean |x0 - x0_hat|^p."""
+        from . import ops
+        x_noisy = self.q_sample(x_start, t, noise)
+        x_recon = self.denoise_fn(audio, t, x_noisy, *cond)
+        xs = x_start[:, : x_recon.shape[1]].float().contiguous()
+        return ops.mean_diff(xs, x_recon.contiguous(), l1=(self.loss_type == "l1"))[0], x_recon
 
     def _split_cond(self, cond):
         m = self.denoise_fn
@@ -364,8 +383,10 @@ class GaussianDiffusion(nn.Module):
         x_T = torch.randn(latent_motion_shape, device=plan.device) if x_T is None else x_T.to(plan.device)
         return plan.sample_ddim(x_T.float().contiguous(), steps, cfg_scale=scale)
 
-    def forward(self, *a, **k):
-        raise FdmError("training (p_losses / backward) is out of scope of the sampling hot path (SURVEY.md section 2, row 22)")
+    def forward(self, x, audio, *cond):
+        """Forward-only loss (:757-761); there is no backward pass on this path (training is out of scope)."""
+        t = torch.randint(0, self.num_timesteps, (1,), device=x.device).long().expand(x.shape[0])
+        return self.p_losses(x, t, audio, *cond)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -384,8 +405,10 @@ class VQAutoEncoder(ParamTree):
         self.preset = replace(base, name=f"vq_{base.name}_{args.in_dim}_{args.face_quan_num}", G=args.face_quan_num,
                               c=args.zquant_dim, V3=args.in_dim, n_books=max(1, args.n_embed // 256))
         presets.PRESETS[self.preset.name] = self.preset
-        for k, v in synth.make_vq_weights(self.preset.name).items():
+        for k, v in synth.make_vq_weights(self.preset.name, encoder=True).items():
             self._register(k, v)
+        self._register("encoder.encoder_pos_embedding.pe",
+                       schedule.positional_table(presets.VQ_HIDDEN, "sinus", 1, 5000).unsqueeze(1), buffer=True)
         self._register("decoder.decoder_pos_embedding.pe",
                        schedule.positional_table(presets.VQ_HIDDEN, "sinus", 1, 5000).unsqueeze(1), buffer=True)
         self._dtype = compute_dtype(dtype)
@@ -398,10 +421,12 @@ class VQAutoEncoder(ParamTree):
             self._plan_stale = False
         return self._plan
 
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        # the training-only encoder.* tensors of a reference checkpoint are not part of the sampling path
-        sd = {k: v for k, v in state_dict.items() if not k.startswith("encoder.")}
-        return super().load_state_dict(sd, strict=strict, **kw)
+    def encode(self, x, one_hot=None):
+        """x [B, L, V3] (vertices minus template) -> latent [B, L*G, c] (models/vq_vae_vocaset.py:23-28)."""
+        if not x.is_cuda:
+            raise FdmError("VQAutoEncoder.encode runs on the HIP path only")
+        emo = None if one_hot is None else one_hot.reshape(-1, one_hot.shape[-1])
+        return self.plan(x.device).encode(x, emo)
 
     def quant(self, x, one_hot=None):
         """-> (z_q [B, c, L*G], emb_loss, (perplexity, min_encodings, indices)); the training-only

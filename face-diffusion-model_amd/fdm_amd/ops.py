@@ -130,6 +130,14 @@ def time_groupnorm(x, gamma, beta, B, T, C, *, y_f32=None, y_t=None, eps=1e-5, a
     check(lib().fdm_op_time_groupnorm(_p(x), _p(gamma), _p(beta), _p(y_f32), _p(y_t), B, T, C, eps, act, dtype, stream()))
 
 
+def mean_diff(a, b, l1=False):
+    """mean((a - b)^2) or mean(|a - b|) as a 1-element device tensor."""
+    partial = torch.empty(1024, device=a.device)
+    out = torch.empty(1, device=a.device)
+    check(lib().fdm_op_mean_diff(_p(a), _p(b), _p(partial), _p(out), a.numel(), int(l1), stream()))
+    return out
+
+
 def adain(content, style, out, NC, Lc, Ls, eps=1e-5):
     check(lib().fdm_op_adain(_p(content), _p(style), _p(out), NC, Lc, Ls, eps, stream()))
 

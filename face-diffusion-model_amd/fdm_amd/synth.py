@@ -134,6 +134,36 @@ def vq_shapes(preset, hidden=VQ_HIDDEN, n_layers=VQ_LAYERS, ffn=VQ_FFN):
     return s
 
 
+def vq_encoder_shapes(preset, hidden=VQ_HIDDEN, n_layers=VQ_LAYERS, ffn=VQ_FFN):
+    """encoder.* parameters (models/vq_vae_vocaset.py:134-191, models/vq_vae_emotion.py:130-196, models/vq_vae.py)."""
+    p = _pd(preset)
+    s = {"encoder.vertice_mapping.0.weight": (hidden, p["V3"]), "encoder.vertice_mapping.0.bias": (hidden,),
+         "encoder.squasher.0.0.weight": (hidden, hidden, 5), "encoder.squasher.0.0.bias": (hidden,),
+         "encoder.encoder_linear_embedding.net.weight": (hidden, hidden),
+         "encoder.encoder_linear_embedding.net.bias": (hidden,)}
+    if p["n_books"] > 1:
+        s["encoder.emotion_mapping.0.weight"] = (hidden, 7)
+        s["encoder.emotion_mapping.0.bias"] = (hidden,)
+    if p["vq_pre"]:
+        s["encoder.encoder_linear_embedding_post.net.weight"] = (p["G"] * p["c"], hidden)
+        s["encoder.encoder_linear_embedding_post.net.bias"] = (p["G"] * p["c"],)
+    for l in range(n_layers):
+        a = f"encoder.encoder_transformer.net.{2 * l}.fn."
+        m = f"encoder.encoder_transformer.net.{2 * l + 1}.fn."
+        s[a + "norm.weight"] = (hidden,)
+        s[a + "norm.bias"] = (hidden,)
+        s[a + "fn.to_qkv.weight"] = (3 * hidden, hidden)
+        s[a + "fn.to_out.weight"] = (hidden, hidden)
+        s[a + "fn.to_out.bias"] = (hidden,)
+        s[m + "norm.weight"] = (hidden,)
+        s[m + "norm.bias"] = (hidden,)
+        s[m + "fn.l1.weight"] = (ffn, hidden)
+        s[m + "fn.l1.bias"] = (ffn,)
+        s[m + "fn.l2.weight"] = (hidden, ffn)
+        s[m + "fn.l2.bias"] = (hidden,)
+    return s
+
+
 def _is_norm(name):
     return ("norm" in name) and ("to_" not in name)
 
@@ -177,8 +207,11 @@ def make_wav2vec_weights(n_layers=12, seed=0, prefix=""):
     return make_weights(wav2vec_shapes(n_layers), seed, prefix)
 
 
-def make_vq_weights(preset, seed=0):
-    return make_weights(vq_shapes(preset), seed)
+def make_vq_weights(preset, seed=0, encoder=False):
+    w = make_weights(vq_shapes(preset), seed)
+    if encoder:
+        w.update(make_weights(vq_encoder_shapes(preset), seed))
+    return w
 
 
 def synth_inputs(preset, B, L, seed=1, audio_frames=None):

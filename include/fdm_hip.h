@@ -159,6 +159,9 @@ int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L,
  * wav2vec2-base (transformers Wav2Vec2GroupNormConvLayer; BIWI audio encoder, models/wav2vec.py:69-143) */
 int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, int B, int T, int C,
                           float eps, int act, int dtype, void* stream);
+/* out[0] = mean(|a - b|^p), p = 2 (l1 = 0) or 1: the forward value of p_losses' F.mse_loss / F.l1_loss
+ * (diffusion_BIWI_encoder_decoder.py:744-749); partial: >= 1024 floats of scratch; deterministic order */
+int fdm_op_mean_diff(const float* a, const float* b, float* partial, float* out, long long n, int l1, void* stream);
 /* AdaIN (utiles/adaIN.py:4-22): content, style [N, C, Lc], [N, C, Ls] -> out [N, C, Lc] */
 int fdm_op_adain(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps, void* stream);
 /* regroup [B, T, d] -> [groups, B, T + 2*pad, d/groups] zero padded (HuBERT positional conv input) */

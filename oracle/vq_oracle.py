@@ -85,6 +85,46 @@ def decode_clip(w, preset, zq, pe_index=0, trace=None):
                     w.get("decoder.vertice_map_reverse.bias"))
 
 
+def _transformer(w, prefix, h):
+    """6 pre-LN blocks of models/lib/base_models.py:177-227 (attention scale hidden^-0.5, tanh-GELU MLP)."""
+    d, H = VQ_HIDDEN, VQ_HEADS
+    L, hd = h.shape[0], d // H
+    for l in range(VQ_LAYERS):
+        a = f"{prefix}.net.{2 * l}.fn."
+        m = f"{prefix}.net.{2 * l + 1}.fn."
+        x = F.layer_norm(h, (d,), w[a + "norm.weight"], w[a + "norm.bias"], 1e-5)
+        q, k, v = [t.view(L, H, hd).transpose(0, 1) for t in F.linear(x, w[a + "fn.to_qkv.weight"]).split(d, dim=1)]
+        o = torch.bmm(torch.softmax(torch.bmm(q, k.transpose(1, 2)) * (d ** -0.5), dim=-1), v).transpose(0, 1).reshape(L, d)
+        h = h + F.linear(o, w[a + "fn.to_out.weight"], w[a + "fn.to_out.bias"])
+        x = F.layer_norm(h, (d,), w[m + "norm.weight"], w[m + "norm.bias"], 1e-5)
+        h = h + F.linear(gelu_tanh(F.linear(x, w[m + "fn.l1.weight"], w[m + "fn.l1.bias"])), w[m + "fn.l2.weight"], w[m + "fn.l2.bias"])
+    return h
+
+
+def encode_clip(w, preset, x, emo=None):
+    """x [L, V3] (vertices minus template) -> latent [L*G, c]
+    (VQAutoEncoder.encode + TransformerEncoder.forward: models/vq_vae_vocaset.py:23-28,134-191,
+    models/vq_vae_emotion.py:20-26,130-196; pe[0] as in decode)."""
+    p = PRESETS[preset]
+    d = VQ_HIDDEN
+    h = F.leaky_relu(F.linear(x, w["encoder.vertice_mapping.0.weight"], w["encoder.vertice_mapping.0.bias"]), 0.2)
+    if p["n_books"] > 1:
+        h = h + F.leaky_relu(F.linear(emo, w["encoder.emotion_mapping.0.weight"], w["encoder.emotion_mapping.0.bias"]), 0.2)
+    xc = F.conv1d(F.pad(h.t().unsqueeze(0), (2, 2), mode="replicate"), w["encoder.squasher.0.0.weight"], w["encoder.squasher.0.0.bias"])
+    h = F.instance_norm(F.leaky_relu(xc, 0.2), eps=1e-5)[0].t()
+    h = F.linear(h, w["encoder.encoder_linear_embedding.net.weight"], w["encoder.encoder_linear_embedding.net.bias"])
+    pe = torch.zeros(d)
+    pe[1::2] = 1.0
+    h = _transformer(w, "encoder.encoder_transformer", h + pe)
+    if p["vq_pre"]:
+        h = F.linear(h, w["encoder.encoder_linear_embedding_post.net.weight"], w["encoder.encoder_linear_embedding_post.net.bias"])
+    return h.reshape(-1, p["c"])
+
+
+def encode(w, preset, x, emo=None):
+    return torch.stack([encode_clip(w, preset, x[b], None if emo is None else emo[b]) for b in range(x.shape[0])])
+
+
 def decode(w, preset, zq):
     """zq [B, c, L*G] -> [B, L, V3]; every clip decoded as a bs = 1 reference call (pe[0])."""
     return torch.stack([decode_clip(w, preset, zq[b]) for b in range(zq.shape[0])])

@@ -437,6 +437,40 @@ def g11_wav2vec():
     save("wav2vec", **out)
 
 
+def g12_vq_encode():
+    """VQ-VAE encoders: encode -> quant -> decode round trip on the reference."""
+    from models.utils.config import vocaset_vq_vae_args, vq_vae_args, biwi_vq_vae_args
+    from models.vq_vae_vocaset import VQAutoEncoder as V1
+    from models.vq_vae_emotion import VQAutoEncoder as V2
+    from models.vq_vae import VQAutoEncoder as V3
+    out = {}
+    for preset, V, args in (("vocaset", V1, vocaset_vq_vae_args()), ("mead", V2, vq_vae_args()), ("biwi", V3, biwi_vq_vae_args())):
+        p = W.PRESETS[preset]
+        ae = V(args).eval()
+        wd = W.make_vq_weights(preset, encoder=True)
+        sd = ae.state_dict()
+        assert set(k for k in sd if not k.endswith(".pe")) == set(wd), set(sd) ^ set(wd)
+        ae.load_state_dict(wd, strict=False)
+        L = 10
+        g = torch.Generator().manual_seed(60)
+        x = torch.randn(1, L, p["V3"], generator=g) * 0.3    # O(1) mapped features: keeps InstanceNorm well conditioned next to the emotion offset
+        emo = torch.eye(7)[5] if p["n_books"] > 1 else None
+        if emo is not None:
+            h = ae.encode(x, emo)
+            oh = VO.encode(wd, preset, x, emo.unsqueeze(0))
+            zq, _, info = ae.quant(h, emo)
+        else:
+            h = ae.encode(x)
+            oh = VO.encode(wd, preset, x)
+            zq, _, info = ae.quant(h)
+        dec = ae.decode(zq)[0]
+        print(f"  {preset}: encode |ref-oracle|={mad(h, oh):.3e} |h|max={float(h.abs().max()):.2f}")
+        out[f"{preset}_h"] = h[0].numpy()
+        out[f"{preset}_idx"] = info[2].numpy().astype(np.int16)
+        out[f"{preset}_dec_cols16"] = dec[:, ::16].numpy()
+    save("vq_encode", **out)
+
+
 ALL = {
     "schedule": g1_schedule, "masks": g2_masks,
     "fdm_step_vocaset": lambda: g3_fdm_step("vocaset"),
@@ -446,7 +480,7 @@ ALL = {
     "chains_vocaset": lambda: g4_chains("vocaset"),
     "chains_mead": lambda: g4_chains("mead"),
     "chains_vocaset_tiny": lambda: g4_chains("vocaset_tiny"),
-    "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio, "state_keys": g10_state_keys, "wav2vec": g11_wav2vec,
+    "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio, "state_keys": g10_state_keys, "wav2vec": g11_wav2vec, "vq_encode": g12_vq_encode,
 }
 
 if __name__ == "__main__":

@@ -65,9 +65,8 @@ def test_mead_and_vq_state_dicts(dropin, ref_keys):
     assert [p for p in inspect.signature(FDM.forward).parameters][1:6] == ["audio", "t", "vertice", "emotion_one_hot", "id_one_hot"]
     for name, V, args in (("vq_vocaset", V1, vocaset_vq_vae_args()), ("vq_mead", V2, vq_vae_args()), ("vq_biwi", V3, biwi_vq_vae_args())):
         ae = V(args)
-        ref = {k: v for k, v in ref_keys[name].items() if not k.startswith("encoder.")}
-        assert shapes(ae) == ref, name
-        ae.load_state_dict({k: torch.zeros(v) for k, v in ref_keys[name].items()})      # strict, encoder.* tolerated
+        assert shapes(ae) == ref_keys[name], name                                        # encoder.* included
+        ae.load_state_dict({k: torch.zeros(v) for k, v in ref_keys[name].items()})      # strict
 
 
 def test_schedule_helpers_and_cli_flags(dropin):

@@ -155,3 +155,43 @@ def test_wav2vec2_base_vs_golden(golden):
     assert mad(p12.forward(wv(10, 160000))[0, ::8], g["out_L12_10s_rows8"]) < 1e-4
     pb = HubertPlan(W.make_wav2vec_weights(12), 12, BF16, DEV, cfg=WAV2VEC2_BASE)
     assert mad(pb.forward(wv(2, 32000))[0], g["out_L12_2s"]) < 0.15
+
+
+@pytest.mark.parametrize("preset", ["vocaset", "mead", "biwi"])
+def test_vq_encode_round_trip_vs_golden(golden, preset):
+    """encode -> quant -> decode on the HIP path vs the reference's own round trip (tests/golden/vq_encode.npz)."""
+    g = golden("vq_encode")
+    p = W.PRESETS[preset]
+    plan = VQPlan(preset, W.make_vq_weights(preset, encoder=True), F32, DEV)
+    x = torch.randn(1, 10, p["V3"], generator=torch.Generator().manual_seed(60)) * 0.3
+    emo = torch.eye(7)[5].unsqueeze(0) if p["n_books"] > 1 else None
+    h = plan.encode(x.to(DEV), None if emo is None else emo.to(DEV))
+    assert mad(h[0], g[f"{preset}_h"]) < 1e-4
+    zq, idx = plan.quant(h, emo)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int16), g[f"{preset}_idx"])
+    assert mad(plan.decode(zq)[0][:, ::16], g[f"{preset}_dec_cols16"]) < 1e-4
+
+
+def test_q_sample_and_forward_loss():
+    """GaussianDiffusion.q_sample / p_losses forward value on the HIP path vs the oracle."""
+    import sys, os
+    from fdm_amd.modules import FDM, GaussianDiffusion
+    from oracle import fdm_oracle as FO
+    model = FDM(feature_dim=1024, audio_encoder=False)
+    w = W.make_fdm_weights("vocaset")
+    model.load_state_dict(w, strict=False)
+    diff = GaussianDiffusion(model, timesteps=1000, loss_type="l2")
+    L, t = 9, 321
+    inp = W.synth_inputs("vocaset", 1, L, seed=12)
+    model.set_audio_features(inp["hub"].to(DEV))
+    x0 = inp["x"].to(DEV)
+    z = torch.randn(x0.shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    tt = torch.full((1,), t, dtype=torch.long, device=DEV)
+    buf = FO.schedule_buffers()
+    xn_ref = buf["sqrt_alphas_cumprod"][t] * inp["x"] + buf["sqrt_one_minus_alphas_cumprod"][t] * z.cpu()
+    xn = diff.to(DEV).q_sample(x0, tt, z)
+    assert torch.equal(xn.cpu(), xn_ref)                                  # same unfused fp32 expression: bit-exact
+    loss, x_recon = diff.p_losses(x0, tt, torch.zeros(1, 16, device=DEV), inp["style"].to(DEV), noise=z)
+    ref = FO.fdm_forward(w, "vocaset", inp["hub"], t, xn_ref, inp["style"], None, folded=True)
+    assert mad(x_recon, ref) < 1e-4
+    assert abs(float(loss) - float(torch.nn.functional.mse_loss(inp["x"], ref))) < 1e-5

@@ -162,3 +162,18 @@ def test_wav2vec2_base(golden):
     wav = HO.processor_normalize(torch.randn(32000, generator=gen) * 0.1)
     assert mad(WO.wav2vec_forward_clip(W.make_wav2vec_weights(2), wav, 2), g["out_L2_2s"]) < TOL
     assert mad(WO.wav2vec_forward_clip(W.make_wav2vec_weights(12), wav, 12), g["out_L12_2s"]) < TOL
+
+
+@pytest.mark.parametrize("preset", ["vocaset", "mead", "biwi"])
+def test_vq_encode_round_trip(golden, preset):
+    """VQ-VAE encoder: encode -> quant -> decode as the reference's stage-1 round trip."""
+    g = golden("vq_encode")
+    p = W.PRESETS[preset]
+    w = W.make_vq_weights(preset, encoder=True)
+    x = torch.randn(1, 10, p["V3"], generator=torch.Generator().manual_seed(60)) * 0.3
+    emo = torch.eye(7)[5].unsqueeze(0) if p["n_books"] > 1 else None
+    h = VO.encode(w, preset, x, emo)
+    assert mad(h[0], g[f"{preset}_h"]) < TOL
+    zq, idx = VO.quant(w, preset, h, emo)
+    assert np.array_equal(idx.numpy().astype(np.int16), g[f"{preset}_idx"])
+    assert mad(VO.decode(w, preset, zq)[0][:, ::16], g[f"{preset}_dec_cols16"]) < TOL
