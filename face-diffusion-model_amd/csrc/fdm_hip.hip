@@ -100,6 +100,10 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (a->out_vt && (a->vt_hd <= 0 || a->vt_L <= 0 || a->vt_Lpad < a->vt_L || a->vt_col0 < 0 || (a->N - a->vt_col0) % a->vt_hd || a->vt_col0 % 4))
     return fail(FDM_ERR_SHAPE, "gemm: bad V^T tail");
   if (a->bias && !aligned16(a->bias)) return fail(FDM_ERR_ARG, "gemm: bias must be 16-byte aligned");
+  if (a->ln_stat_in && (a->ln_nparts <= 0 || a->ln_dim <= 0)) return fail(FDM_ERR_ARG, "gemm: ln_stat_in needs ln_nparts and ln_dim");
+  if ((a->ln_colsum || a->rln_gamma) && !a->ln_stat_in) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding needs ln_stat_in");
+  if (a->rln_gamma && (!a->rln_beta || !a->resid)) return fail(FDM_ERR_ARG, "gemm: rln_gamma needs rln_beta and resid");
+  if ((a->stat_out || a->ln_stat_in) && (a->batch > 1 || a->out_batch_stride)) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding is not batched");
   fdm_gemm_args c = *a;
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
 }

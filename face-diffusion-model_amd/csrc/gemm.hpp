@@ -21,11 +21,56 @@
 
 namespace fdm {
 
+// LDS scratch of the LayerNorm-folding epilogue: rowstat[BM][2] (mu, rstd of this block's rows) followed by
+// the cross-wave combine area [WN][BM][2]
+template <int BM, int WN> constexpr int gemm_ln_scratch_bytes() { return BM * 2 * (1 + WN) * 4; }
+
+// Consumer side: mu / rstd of the block's rows from the producer's per-64-column partial sums (fixed order).
+template <int BM>
+__device__ __forceinline__ void gemm_load_rowstats(const fdm_gemm_args& p, int m0, float* rowstat) {
+  if (!p.ln_stat_in) return;
+  const int t = threadIdx.x;
+  if (t < BM) {
+    const int m = min(m0 + t, p.M - 1);
+    float s = 0.f, q = 0.f;
+    // issue all partial loads before the first use (one L2 round trip instead of ln_nparts of them)
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    for (int i0 = 0; i0 < p.ln_nparts; i0 += 16) {
+      f32x2 v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ii = min(i0 + i, p.ln_nparts - 1);
+        v[i] = *(const f32x2*)(p.ln_stat_in + ((size_t)ii * p.M + m) * 2);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (i0 + i < p.ln_nparts) { s += v[i][0]; q += v[i][1]; }
+    }
+    const float inv = 1.f / (float)p.ln_dim;
+    const float mu = s * inv;
+    const float var = fmaxf(q * inv - mu * mu, 0.f);
+    rowstat[2 * t] = mu;
+    rowstat[2 * t + 1] = 1.f / sqrtf(var + p.ln_eps);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes are ordered by the k loop's first raw s_barrier
+}
+
 template <typename T, int BM, int BN, int WM = 2, int WN = 2>
 __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0, int z,
-                                              int wm, int wn, int g, int r16) {
+                                              int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   const int M = p.M, N = p.N;
+  // Whole-tile V^T fast path: stage the tile transposed in LDS ([n][m], the ring is free after the k loop) and
+  // store 16-byte runs along l.  Needs the tile to lie entirely in the V columns and clip boundaries on
+  // 16-byte multiples (L % (16 / sizeof(T)) == 0); otherwise the per-element scatter below is used.
+  constexpr int EPC_T = 16 / (int)sizeof(T);
+  const bool vt_tile = tile_lds && p.out_vt && n0 >= p.vt_col0 && n0 + BN <= N && (p.vt_L % EPC_T == 0) &&
+                       (p.vt_Lpad % EPC_T == 0) && (p.vt_hd % 4 == 0);
+  T* tl = (T*)tile_lds;
+  if (vt_tile) __syncthreads();      // every wave is done reading the last ring stage
+  float* comb = rowstat ? rowstat + BM * 2 : nullptr;
+  const bool use_ln = rowstat && p.ln_stat_in;
+  const bool do_stat = rowstat && p.stat_out;
   // ---- fused epilogue: lane owns C[m = .. + r16][n = .. + 4g + (0..3)] ----
   const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
   const size_t ocol = (size_t)z * p.out_batch_stride;
@@ -35,15 +80,27 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   const int vt_H = p.out_vt ? (N - p.vt_col0) / p.vt_hd : 0;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
-    const int m = m0 + wm * (BM / WM) + mi * 16 + r16;
+    const int lrow = wm * (BM / WM) + mi * 16 + r16;
+    const int m = m0 + lrow;
     if (m >= M) continue;
     const size_t rrow = p.resid_row_mod > 0 ? (size_t)(m % p.resid_row_mod) : (size_t)m;
+    const float mu = use_ln ? rowstat[2 * lrow] : 0.f, rs = use_ln ? rowstat[2 * lrow + 1] : 1.f;
+    float ps = 0.f, pq = 0.f;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * g;
       if (n >= N) continue;
       f32x4 v = acc[mi][ni];
       const bool full = (n + 3 < N);
+      if (use_ln && p.ln_colsum) {      // LN(x) W^T == rstd (x W'^T - mu colsum(W'))
+        if (full) {
+          const f32x4 cs = *(const f32x4*)(p.ln_colsum + n);
+          v = (v - mu * cs) * rs;
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (n + j < N) v[j] = (v[j] - mu * p.ln_colsum[n + j]) * rs;
+        }
+      }
       if (bias) {
         if (full) {
           f32x4 b = *(const f32x4*)(bias + n);
@@ -59,12 +116,30 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       }
       if (p.resid) {
         const float* rp = p.resid + ocol + rrow * p.ldr + n;
-        if (full && vec_r) {
+        if (use_ln && p.rln_gamma) {    // residual = LayerNorm(raw row) computed on the fly
+          if (full && vec_r) {
+            const f32x4 xr = *(const f32x4*)rp, gm = *(const f32x4*)(p.rln_gamma + n), bt = *(const f32x4*)(p.rln_beta + n);
+            v += (xr - mu) * rs * gm + bt;
+          } else {
+            for (int j = 0; j < 4; ++j)
+              if (n + j < N) v[j] += (rp[j] - mu) * rs * p.rln_gamma[n + j] + p.rln_beta[n + j];
+          }
+        } else if (full && vec_r) {
           v += *(const f32x4*)rp;
         } else {
           for (int j = 0; j < 4; ++j)
             if (n + j < N) v[j] += rp[j];
         }
+      }
+      if (do_stat) {
+        for (int j = 0; j < 4; ++j)
+          if (n + j < N) { ps += v[j]; pq += v[j] * v[j]; }
+      }
+      if (vt_tile) {
+        const int nl = wn * (BN / WN) + ni * 16 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<T>(v[j]);
+        continue;
       }
       if (p.out_vt && n >= p.vt_col0) {
         // scatter transposed: Vt[((b*H + h)*hd + e)*Lpad + l]
@@ -102,6 +177,36 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         }
       }
     }
+    if (do_stat) {     // the 4 lane groups of a row hold disjoint columns: fold them, one lane stores the wave's partial
+      ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+      pq += __shfl_xor(pq, 16, 64); pq += __shfl_xor(pq, 32, 64);
+      if (g == 0) { comb[(wn * BM + lrow) * 2] = ps; comb[(wn * BM + lrow) * 2 + 1] = pq; }
+    }
+  }
+  if (vt_tile) {
+    __syncthreads();
+    constexpr int CPR = BM / EPC_T;                       // 16-byte chunks per tile column
+    for (int c = threadIdx.x; c < BN * CPR; c += WM * WN * 64) {
+      const int nl = c / CPR, ml = (c % CPR) * EPC_T;
+      const int m = m0 + ml;
+      if (m >= M) continue;                               // M is a multiple of L, L of EPC_T: chunks are all-in or all-out
+      const int b = m / p.vt_L, l = m - b * p.vt_L;
+      const int cc = n0 + nl - p.vt_col0;
+      const int h = cc / p.vt_hd, e = cc - h * p.vt_hd;
+      *(u32x4*)((T*)p.out_vt + ((size_t)(b * vt_H + h) * p.vt_hd + e) * p.vt_Lpad + l) = *(const u32x4*)(tl + nl * BM + ml);
+    }
+  }
+  if (do_stat) {
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < BM && m0 + t < M) {
+      float s = 0.f, q = 0.f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) { s += comb[(w * BM + t) * 2]; q += comb[(w * BM + t) * 2 + 1]; }
+      float* so = p.stat_out + ((size_t)(n0 / 64) * M + (m0 + t)) * 2;
+      so[0] = s; so[1] = q;
+      if (BN > 64 && n0 + 64 < N) { so[2 * (size_t)M] = 0.f; so[2 * (size_t)M + 1] = 0.f; }   // 128-wide tiles own two slots
+    }
   }
 }
 
@@ -115,6 +220,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const fdm_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *p.incr_counter += 1;
   const int wm = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, r16 = lane & 15;
   const int z = blockIdx.z;
@@ -226,8 +332,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   constexpr int P = A_IPW + W_IPW;
   constexpr int STAGE = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
 
   const int tid = threadIdx.x, lane = tid & 63;
+  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *p.incr_counter += 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r16 = lane & 15;
@@ -274,6 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) issue(t);
+  gemm_load_rowstats<BM>(p, m0, rowstat);   // visible to every wave after the first barrier of the k loop
 
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most the (NST-2) younger tiles of this wave are still in flight
@@ -301,13 +410,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
         for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], af[mi]);
     }
   }
-  gemm_epilogue<T, BM, BN, WM, WN>(p, acc, m0, n0, z, wm, wn, g, r16);
+  gemm_epilogue<T, BM, BN, WM, WN>(p, acc, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
 static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
-  constexpr int lds = NST * (BM + BN) * KCH * 16;
+  constexpr int lds = NST * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, WN>();
   static bool once = [] {
     return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();
@@ -335,7 +444,10 @@ template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   const long long batch = a.batch > 0 ? a.batch : 1;
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
-  if (gemm_variant() == 0) return t128 >= 384 ? gemm_launch_t<T, 128, 128>(a, s) : gemm_launch_t<T, 64, 64>(a, s);
+  if (gemm_variant() == 0) {
+    if (a.stat_out || a.ln_stat_in) return hipErrorInvalidValue;      // LayerNorm folding lives in the ring kernels only
+    return t128 >= 384 ? gemm_launch_t<T, 128, 128>(a, s) : gemm_launch_t<T, 64, 64>(a, s);
+  }
   switch (gemm_variant()) {
     case 2: return gemm_glds_launch_t<T, 64, 64, 2, 2, 4>(a, s);     // 4 waves, 32x32 per wave
     case 3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave

@@ -20,7 +20,9 @@ class GemmArgs(C.Structure):
                 ("resid", vp), ("ldr", ll), ("resid_row_mod", ci),
                 ("out_f32", vp), ("ldo_f32", ll), ("out_t", vp), ("ldo_t", ll),
                 ("out_batch_stride", ll),
-                ("out_vt", vp), ("vt_col0", ci), ("vt_L", ci), ("vt_Lpad", ci), ("vt_hd", ci)]
+                ("out_vt", vp), ("vt_col0", ci), ("vt_L", ci), ("vt_Lpad", ci), ("vt_hd", ci),
+                ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
+                ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp)]
 
 
 class AttnArgs(C.Structure):

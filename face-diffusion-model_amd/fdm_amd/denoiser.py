@@ -15,8 +15,10 @@ What runs where
       fused causal-ALiBi attention -> out-proj GEMM(+bias+residual) -> fused LN1+LN2(+C1_l + TT_l[t]) ->
       FFN1 GEMM(+bias+ReLU) -> FFN2 GEMM(+bias+residual) -> LN3 } -> latent_decoder GEMM ->
       fused scheduler update (DDPM / DDIM, optional CFG mix, Philox or injected noise; also writes the
-      operand-dtype copy of x_{t-1} for the next step and advances the device-side step counter):
-      51 kernel launches per diffusion step.
+      operand-dtype copy of x_{t-1} for the next step); the device-side step counter is advanced by one
+      thread of the step's first GEMM:
+      51 kernel launches per diffusion step; 43 in bf16 mode, where norm3 is folded into the QKV / out-proj /
+      latent-decoder GEMMs through per-row partial sums written by the FFN2 epilogue.
 torch only owns the device buffers and the stream."""
 import math
 import os
@@ -76,6 +78,21 @@ class DenoiserPlan:
                 ops.gemm(tmp, Wo, 1000, d, d, out_f32=tt)
                 self.TT.append(tt)
                 self.Wv.append(Wv); self.bv.append(bv); self.Wo.append(Wo); self.bo.append(bo)
+            # bf16 step program: norm3 of layer l-1 folded into the QKV / out-proj GEMMs of layer l and into the
+            # latent decoder (LN(x) W^T + b = rstd (x W'^T - mu colsum(W')) + (W beta + b), W' = W o gamma)
+            self.fuse_ln3 = dtype == BF16 and os.environ.get("FDM_FUSE_LN3", "1") == "1"
+            self.fold = {}
+            if self.fuse_ln3:
+                def fold(wname, bname, l_prev):
+                    pre = f"transformer_decoder.layers.{l_prev}.norm3."
+                    gam, bet = w[pre + "weight"], w[pre + "bias"]
+                    wp = ops.to_operand((w[wname] * gam.unsqueeze(0)).contiguous(), dtype)
+                    return dict(w=wp, colsum=wp.float().sum(1).contiguous(), bias=(w[wname] @ bet + w[bname]).contiguous(),
+                                gamma=gam, beta=bet)
+                for l in range(1, p.n_layers):
+                    pre = f"transformer_decoder.layers.{l}.self_attn."
+                    self.fold[l] = fold(pre + "in_proj_weight", pre + "in_proj_bias", l - 1)
+                self.fold["dec"] = fold("latent_decoder.weight", "latent_decoder.bias", p.n_layers - 1)
             self.slopes = torch.tensor(schedule.alibi_slopes(p.n_head), dtype=torch.float32).to(dv)
             self.pe = schedule.positional_table(d, p.pe, p.period, p.max_len + 30).to(dv)
         self.stream.synchronize()
@@ -178,11 +195,12 @@ class DenoiserPlan:
             ws.update(xt=z(self.M, d, dt=td), ht=z(R, d, dt=td), h2t=z(R, d, dt=td))
         else:   # fp32 operands alias the fp32 residual-stream buffers
             ws.update(xt=ws["x"], ht=ws["h"], h2t=ws["h2"])
+        if self.fuse_ln3:
+            ws.update(x2=z(R, d), x2t=z(R, d, dt=td), stats=z(self.chains, d // 64, self.Rc, 2))
         ws.update(qkv=z(R, 3 * d, dt=td), ctx=z(R, d, dt=td), u=z(R, p.ffn, dt=td),
                   vt=z(self.B * self.rep * p.n_head, p.head_dim, self.Lpad, dt=td))
         self.ws = ws
         self.step = torch.zeros(self.chains, dtype=torch.int32, device=dv)      # one device-side step counter per chain
-        self.arrive = torch.zeros(self.chains, dtype=torch.int32, device=dv)    # ticket words of the in-kernel advance
         self.tseq = torch.zeros(1024, dtype=torch.int32, device=dv)
 
     # ------------------------------------------------------------------------------------------
@@ -199,18 +217,33 @@ class DenoiserPlan:
             o = rb + r * Mc
             ops.gemm(ws["xt"][xr:], wt["latent_encoder.0.weight"], Mc, d, d, bias=w["latent_encoder.0.bias"],
                      act=ACT_MISH if p.latent_mish else ACT_NONE, resid=self.E0[o:], out_f32=ws["h"][o:],
-                     out_t=ws["ht"][o:] if both else None)
+                     out_t=ws["ht"][o:] if both else None,
+                     incr_counter=step if r == 0 else None)      # first kernel of the step: step counter += 1
         BBc = Bc * self.rep
         vt = ws["vt"][c * BBc * p.n_head:]
+        fuse = self.fuse_ln3
+        st = ws["stats"][c] if fuse else None
+        np_, eps = d // 64, 1e-5
         for l in range(p.n_layers):
             pre = f"transformer_decoder.layers.{l}."
-            ops.gemm(ws["ht"][rb:], wt[pre + "self_attn.in_proj_weight"], Rc, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"],
-                     out_t=ws["qkv"][rb:], ldo_t=3 * d, out_vt=vt, vt_col0=2 * d, vt_L=L, vt_Lpad=self.Lpad, vt_hd=p.head_dim)
+            f = self.fold.get(l) if fuse else None
+            if f is None:      # layer input h (fp32) / ht (operand copy) are materialised
+                ops.gemm(ws["ht"][rb:], wt[pre + "self_attn.in_proj_weight"], Rc, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"],
+                         out_t=ws["qkv"][rb:], ldo_t=3 * d, out_vt=vt, vt_col0=2 * d, vt_L=L, vt_Lpad=self.Lpad, vt_hd=p.head_dim)
+            else:              # layer input = LN3(x2) of the previous layer, never materialised
+                ops.gemm(ws["x2t"][rb:], f["w"], Rc, 3 * d, d, bias=f["bias"], out_t=ws["qkv"][rb:], ldo_t=3 * d, out_vt=vt,
+                         vt_col0=2 * d, vt_L=L, vt_Lpad=self.Lpad, vt_hd=p.head_dim,
+                         ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
             ops.attention(ws["qkv"][rb:], ws["qkv"][rb:, d:], vt, ws["ctx"][rb:], B=BBc, H=p.n_head, L=L, hd=p.head_dim,
                           ldq=3 * d, ldk=3 * d, ldo=d, Lpad=self.Lpad, scale=1.0 / math.sqrt(p.head_dim), causal=True,
                           slopes=self.slopes, period=p.period)
-            ops.gemm(ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
-                     resid=ws["h"][rb:], out_f32=ws["x1"][rb:])
+            if f is None:
+                ops.gemm(ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
+                         resid=ws["h"][rb:], out_f32=ws["x1"][rb:])
+            else:
+                ops.gemm(ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
+                         resid=ws["x2"][rb:], out_f32=ws["x1"][rb:], ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps,
+                         rln_gamma=f["gamma"], rln_beta=f["beta"])
             # norm1 and norm2 back to back in one kernel: h2 = LN2(LN1(x1) + C1_l + TT_l[t])
             ops.layernorm(ws["x1"][rb:], w[pre + "norm1.weight"], w[pre + "norm1.bias"], Rc, d, add_mat=self.C1[l][rb:],
                           add_tab=self.TT[l], tab_index=self.tseq, tab_step=step, y_f32=ws["h2"][rb:],
@@ -218,11 +251,20 @@ class DenoiserPlan:
                           gamma2=w[pre + "norm2.weight"], beta2=w[pre + "norm2.bias"])
             ops.gemm(ws["h2t"][rb:], wt[pre + "linear1.weight"], Rc, p.ffn, d, bias=w[pre + "linear1.bias"], act=ACT_RELU,
                      out_t=ws["u"][rb:])
-            ops.gemm(ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
-                     out_f32=ws["x1"][rb:])
-            ops.layernorm(ws["x1"][rb:], w[pre + "norm3.weight"], w[pre + "norm3.bias"], Rc, d, y_f32=ws["h"][rb:],
-                          y_t=ws["ht"][rb:] if both else None, dtype=self.dtype)
-        ops.gemm(ws["ht"][rb:], wt["latent_decoder.weight"], Rc, d, d, bias=w["latent_decoder.bias"], out_f32=ws["x0"][rb:])
+            if fuse:           # x2 = h2 + FFN(h2): fp32 + operand copy + per-row partial sums for the folded norm3
+                ops.gemm(ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
+                         out_f32=ws["x2"][rb:], out_t=ws["x2t"][rb:], stat_out=st)
+            else:
+                ops.gemm(ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
+                         out_f32=ws["x1"][rb:])
+                ops.layernorm(ws["x1"][rb:], w[pre + "norm3.weight"], w[pre + "norm3.bias"], Rc, d, y_f32=ws["h"][rb:],
+                              y_t=ws["ht"][rb:] if both else None, dtype=self.dtype)
+        if fuse:
+            f = self.fold["dec"]
+            ops.gemm(ws["x2t"][rb:], f["w"], Rc, d, d, bias=f["bias"], out_f32=ws["x0"][rb:],
+                     ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
+        else:
+            ops.gemm(ws["ht"][rb:], wt["latent_decoder.weight"], Rc, d, d, bias=w["latent_decoder.bias"], out_f32=ws["x0"][rb:])
 
     def _program(self, kind, **kw):
         """Build (once) the step program `kind` in {'pass', 'ddpm', 'ddim'}: one lane per clip group."""
@@ -241,19 +283,18 @@ class DenoiserPlan:
                 x = ws["x"][c * Mc:]
                 xt = ws["xt"][c * Mc:] if self.dtype == BF16 else None
                 step = self.step[c:]
-                arrive = self.arrive[c:]
                 if kind == "ddpm":
                     nz = kw.get("noise")
                     ops.sched_step(0, x0, x, x, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
-                                   n_per_clip=self.L * d, tseq=self.tseq, step=step, advance=1,
+                                   n_per_clip=self.L * d, tseq=self.tseq, step=step, advance=0,
                                    c1=self.c1, c2=self.c2, sigma=self.sigma,
                                    noise=None if nz is None else nz.view(-1)[c * n:], noise_stride=self.M * d,
-                                   seed=kw.get("seed", 0), clip0=kw.get("clip0", 0) + c * self.Bc, x_out_t=xt, arrive=arrive)
+                                   seed=kw.get("seed", 0), clip0=kw.get("clip0", 0) + c * self.Bc, x_out_t=xt)
                 elif kind == "ddim":
                     ops.sched_step(1, x0, x, x, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
-                                   tseq=self.tseq, step=step, advance=1, sra=self.buf["sqrt_recip_alphas_cumprod"],
+                                   tseq=self.tseq, step=step, advance=0, sra=self.buf["sqrt_recip_alphas_cumprod"],
                                    srm1=self.buf["sqrt_recipm1_alphas_cumprod"], sqrt_an=kw["sqrt_an"], c_n=kw["c_n"],
-                                   x_out_t=xt, arrive=arrive)
+                                   x_out_t=xt)
                 elif kind == "pass" and self.cfg:
                     ops.sched_step(2, x0, None, x0, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0))
         prog.hold(*[v for v in kw.values() if torch.is_tensor(v)])
@@ -271,8 +312,7 @@ class DenoiserPlan:
             self.tseq = torch.zeros(len(ts), dtype=torch.int32, device=self.device)
             self._progs = {}
         self.tseq[: len(ts)].copy_(torch.tensor(ts, dtype=torch.int32))
-        self.step.zero_()
-        self.arrive.zero_()
+        self.step.fill_(-1)          # the first GEMM of every step increments it before anything reads it
 
     def _load_x(self, x):
         self.ws["x"].copy_(x.reshape(self.M, self.p.d))

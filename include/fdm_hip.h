@@ -63,6 +63,20 @@ typedef struct fdm_gemm_args {
   void* out_t; long long ldo_t;
   long long out_batch_stride;     /* elements, applied to out_f32, out_t and resid (column offset) */
   void* out_vt; int vt_col0; int vt_L; int vt_Lpad; int vt_hd;
+  /* --- LayerNorm folded into the GEMMs around it (bf16 step program; removes the norm3 launch) ---
+   * producer: stat_out != NULL -> per-row partial (sum v, sum v^2) of the fp32 outputs of each 64-column
+   *   group are written to stat_out[(n/64) * 2M + 2m + {0,1}] (plain stores, fixed order: deterministic).
+   * consumer: ln_stat_in != NULL -> mu_m, rstd_m = f(sum over ln_nparts partials, ln_dim, ln_eps).
+   *   ln_colsum != NULL: A holds the RAW (un-normalised) rows and W = W o gamma, so
+   *     LN(x) W^T + b  ==  rstd_m (acc - mu_m colsum_n) + bias_n   with bias_n := beta.W_n + b_n;
+   *   rln_gamma != NULL: `resid` holds the raw rows and the residual added is LN(resid) computed on the fly. */
+  float* stat_out;
+  const float* ln_stat_in; int ln_nparts; int ln_dim; float ln_eps;
+  const float* ln_colsum;
+  const float* rln_gamma; const float* rln_beta;
+  /* optional device int incremented once (by one thread) when the kernel starts: the first GEMM of a diffusion
+   * step advances the device-side step counter this way (no extra launch, no atomics on a hot word) */
+  int* incr_counter;
 } fdm_gemm_args;
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 

@@ -177,3 +177,20 @@ def _biwi_oracle_clip(w, a_paired, t, x, style):
         f = Fn.linear(torch.relu(Fn.linear(h, w[pre + "linear1.weight"], w[pre + "linear1.bias"])), w[pre + "linear2.weight"], w[pre + "linear2.bias"])
         h = Fn.layer_norm(h + f, (d,), w[pre + "norm3.weight"], w[pre + "norm3.bias"], 1e-5)
     return Fn.linear(h, w["latent_decoder.weight"], w["latent_decoder.bias"]).reshape(L * p["G"], p["c"])
+
+
+def test_bf16_folded_norm3_matches_unfolded(monkeypatch):
+    """bf16 step program with norm3 folded into the surrounding GEMMs vs the same program with the LN3 launches."""
+    L, t = 50, 777
+    inp = W.synth_inputs("vocaset", 2, L, seed=31)
+    w = W.make_fdm_weights("vocaset")
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FDM_FUSE_LN3", flag)
+        plan = DenoiserPlan("vocaset", w, BF16, DEV)
+        assert plan.fuse_ln3 == (flag == "1")
+        plan.prepare(inp["hub"], inp["style"], L=L)
+        outs[flag] = plan.denoise(inp["x"].to(DEV), t).cpu()
+    ref = FO.fdm_forward(w, "vocaset", inp["hub"], t, inp["x"], inp["style"], None, folded=True)
+    assert mad(outs["1"], ref) < TOLBF and mad(outs["0"], ref) < TOLBF
+    assert mad(outs["1"], outs["0"]) < TOLBF

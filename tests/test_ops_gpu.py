@@ -330,3 +330,53 @@ def test_sched_in_kernel_advance_and_operand_copy():
         torch.cuda.synchronize()
         assert int(step[0]) == k + 1 and int(arrive[0]) == 0
     assert torch.equal(out, x0 + x) and torch.equal(outt, (x0 + x).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("M,N", [(800, 3072), (200, 1024), (1992, 1024), (70, 192)])
+def test_gemm_layernorm_folding(dtype, M, N):
+    """LayerNorm folded into the GEMMs around it: producer writes per-64-column partial row sums; the consumer
+    GEMM takes the RAW rows with W o gamma and corrects in the epilogue; a third GEMM adds LN(raw) as residual."""
+    g = torch.Generator().manual_seed(M + N)
+    td = ops.tdtype(dtype)
+    K = 1024
+    tol = 3e-5 if dtype == F32 else 2e-2
+    # --- producer: y0 = A0 W0^T + b0 + r0 with statistics of its fp32 output ---
+    A0 = torch.randn(M, 256, generator=g).to(td)
+    W0 = (torch.randn(K, 256, generator=g) / 16).to(td)
+    b0 = torch.randn(K, generator=g) * 0.3
+    r0 = torch.randn(M, K, generator=g) + 0.2
+    x = torch.zeros(M, K, device=DEV)
+    xt = torch.zeros(M, K, device=DEV, dtype=td)
+    nparts = K // 64
+    stats = torch.full((nparts, M, 2), float("nan"), device=DEV)
+    ops.gemm(A0.to(DEV), W0.to(DEV), M, K, 256, bias=b0.to(DEV), resid=r0.to(DEV), out_f32=x, out_t=xt, stat_out=stats)
+    torch.cuda.synchronize()
+    xr = A0.float() @ W0.float().t() + b0 + r0
+    assert rel(x, xr) < tol
+    sx = x.cpu().view(M, nparts, 64)
+    assert torch.allclose(stats[:, :, 0].cpu().t(), sx.sum(2), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(stats[:, :, 1].cpu().t(), (sx ** 2).sum(2), rtol=1e-4, atol=1e-3)
+    # --- consumer: LN(x) W^T + b via raw rows ---
+    gam = 1 + 0.1 * torch.randn(K, generator=g)
+    bet = 0.1 * torch.randn(K, generator=g)
+    W = torch.randn(N, K, generator=g) / 32
+    b = torch.randn(N, generator=g) * 0.1
+    Wp = (W * gam).to(td)
+    colsum = Wp.float().sum(1).contiguous()
+    bias2 = (W @ bet + b).contiguous()
+    ref = F.layer_norm(x.cpu(), (K,), gam, bet, 1e-5) @ W.t() + b
+    y = torch.zeros(M, N, device=DEV)
+    ops.gemm(xt, Wp.to(DEV), M, N, K, bias=bias2.to(DEV), out_f32=y, ln_stat_in=stats, ln_nparts=nparts, ln_dim=K,
+             ln_colsum=colsum.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(y, ref) < (1e-4 if dtype == F32 else 3e-2)
+    # --- residual = LN(raw rows) on the fly ---
+    A2 = torch.randn(M, 128, generator=g).to(td)
+    W2 = (torch.randn(K, 128, generator=g) / 12).to(td)
+    ref2 = A2.float() @ W2.float().t() + F.layer_norm(x.cpu(), (K,), gam, bet, 1e-5)
+    y2 = torch.zeros(M, K, device=DEV)
+    ops.gemm(A2.to(DEV), W2.to(DEV), M, K, 128, resid=x, out_f32=y2, ln_stat_in=stats, ln_nparts=nparts, ln_dim=K,
+             rln_gamma=gam.to(DEV), rln_beta=bet.to(DEV))
+    torch.cuda.synchronize()
+    assert rel(y2, ref2) < (3e-5 if dtype == F32 else 1e-2)

@@ -54,3 +54,31 @@ def main():
     print(f"cast n={n}: {us:7.2f} us")
 
 main()
+
+
+def fold_costs():
+    """Cost of the LayerNorm-folding epilogue options (bf16, M=800)."""
+    import math
+    dt = torch.bfloat16
+    M, d = 800, 1024
+    A = torch.randn(M, d, device=DEV).to(dt); W3 = (torch.randn(3 * d, d, device=DEV) / 32).to(dt); W1 = (torch.randn(d, 2 * d, device=DEV) / 45).to(dt)
+    U = torch.randn(M, 2 * d, device=DEV).to(dt)
+    b3 = torch.randn(3 * d, device=DEV); b1 = torch.randn(d, device=DEV); res = torch.randn(M, d, device=DEV)
+    qkv = torch.empty(M, 3 * d, device=DEV, dtype=dt); vt = torch.zeros(32, 128, 224, device=DEV, dtype=dt)
+    stats = torch.rand(16, M, 2, device=DEV) * 1000 + 2000; cs = torch.randn(3 * d, device=DEV)
+    o32 = torch.empty(M, d, device=DEV); ot = torch.empty(M, d, device=DEV, dtype=dt)
+    gam = torch.ones(d, device=DEV); bet = torch.zeros(d, device=DEV)
+    kw = dict(out_t=qkv, ldo_t=3 * d, out_vt=vt, vt_col0=2 * d, vt_L=200, vt_Lpad=224, vt_hd=128)
+    print(f"qkv plain (vt scatter)        {timeit(lambda: ops.gemm(A, W3, M, 3 * d, d, bias=b3, **kw)):7.2f} us")
+    print(f"qkv no vt scatter             {timeit(lambda: ops.gemm(A, W3, M, 3 * d, d, bias=b3, out_t=qkv, ldo_t=3 * d)):7.2f} us")
+    print(f"qkv + rowstats + colsum       {timeit(lambda: ops.gemm(A, W3, M, 3 * d, d, bias=b3, ln_stat_in=stats, ln_nparts=16, ln_dim=d, ln_colsum=cs, **kw)):7.2f} us")
+    print(f"ffn2 plain                    {timeit(lambda: ops.gemm(U, W1, M, d, 2 * d, bias=b1, resid=res, out_f32=o32)):7.2f} us")
+    print(f"ffn2 + out_t                  {timeit(lambda: ops.gemm(U, W1, M, d, 2 * d, bias=b1, resid=res, out_f32=o32, out_t=ot)):7.2f} us")
+    print(f"ffn2 + out_t + stat_out       {timeit(lambda: ops.gemm(U, W1, M, d, 2 * d, bias=b1, resid=res, out_f32=o32, out_t=ot, stat_out=stats)):7.2f} us")
+    Wo = (torch.randn(d, d, device=DEV) / 32).to(dt)
+    print(f"out-proj plain                {timeit(lambda: ops.gemm(A, Wo, M, d, d, bias=b1, resid=res, out_f32=o32)):7.2f} us")
+    print(f"out-proj + rln                {timeit(lambda: ops.gemm(A, Wo, M, d, d, bias=b1, resid=res, out_f32=o32, ln_stat_in=stats, ln_nparts=16, ln_dim=d, rln_gamma=gam, rln_beta=bet)):7.2f} us")
+
+
+if len(sys.argv) > 3 and sys.argv[3] == 'fold':
+    fold_costs()
