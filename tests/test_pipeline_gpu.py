@@ -142,3 +142,20 @@ def test_biwi_demo_end_to_end(tmp_path):
     dst = pipeline.demo_main("biwi", ["--audio_file", wp, "--audio_path", str(tmp_path / "result"), "--ddim_steps", "3"])
     arr = np.load(dst)
     assert arr.shape == (1, 49, 70110) and np.isfinite(arr).all()
+
+
+def test_bf16_module_surface_tracks_fp32(monkeypatch):
+    """FDM_AMD_DTYPE=bf16 through the drop-in classes (bf16 step program with folded norm3, bf16 HuBERT and VQ
+    decoder) stays within the stated distance of the fp32 path on a short DDIM run."""
+    from fdm_amd import pipeline
+    gen = torch.Generator().manual_seed(9)
+    wav = HO.processor_normalize(torch.randn(24000, generator=gen) * 0.1).numpy()
+    res = {}
+    for name in ("fp32", "bf16"):
+        monkeypatch.setenv("FDM_AMD_DTYPE", name)
+        diffusion, ae = pipeline.build_models("vocaset", device=DEV)
+        out, latent = pipeline.animate(diffusion, ae, wav, ddim_steps=10, seed=4, device=DEV)
+        assert torch.isfinite(out).all()
+        res[name] = (out.cpu(), latent.cpu())
+    assert res["fp32"][0].shape == (1, 74, 15069)
+    assert mad(res["fp32"][1], res["bf16"][1]) < 0.15          # latents O(4)
