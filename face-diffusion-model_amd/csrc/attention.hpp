@@ -68,29 +68,25 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
   const int kend = p.causal ? min(q0 + 16, L) : L;     // keys [0, kend) can be visible to this tile
   const int ntiles = (kend + KT - 1) / KT;
 
-  // K fragments of a tile are fetched one tile ahead and the V^T fragments at the top of the tile, so the
-  // L2 round trips overlap the MFMAs and the softmax of the current tile instead of serialising with them.
-  auto load_k = [&](int kt, u32x4 (&kf)[NSUB][NKS]) {
+  // Measured: software prefetch of the next tile's fragments (register double buffers, copy or ping-pong) is
+  // SLOWER here (9.1 / 10.4 us vs 8.4 us at cfg2): the extra 64 VGPRs cost residency, and residency is what hides
+  // the L2 round trips of these short per-wave chains.  So each tile simply loads its fragments and uses them.
+  const float inv_period = 1.f / (float)p.period;
+
+  for (int kt = wave; kt < ntiles; kt += 4) {
     const int kbase = kt * KT;
+    u32x4 kcur[NSUB][NKS];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
       // key fed by A-port row r16 of sub-tile s
       const int krow = (NSUB == 2) ? (kbase + 8 * (r16 >> 2) + 4 * s + (r16 & 3)) : (kbase + r16);
       const T* kp = K + (size_t)min(krow, L - 1) * p.ldk;
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) kf[s][ks] = *(const u32x4*)(kp + (ks * 4 + g) * EPC);
+      for (int ks = 0; ks < NKS; ++ks) kcur[s][ks] = *(const u32x4*)(kp + (ks * 4 + g) * EPC);
     }
-  };
-  u32x4 kcur[NSUB][NKS], knext[NSUB][NKS];
-  if (wave < ntiles) load_k(wave, kcur);
-  const float inv_period = 1.f / (float)p.period;
-
-  for (int kt = wave; kt < ntiles; kt += 4) {
-    const int kbase = kt * KT;
     u32x4 vf[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) vf[c] = *(const u32x4*)(Vt + (size_t)(c * 16 + r16) * p.Lpad + kbase + g * EPC);
-    if (kt + 4 < ntiles) load_k(kt + 4, knext);
     f32x4 sc[NSUB];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s) {
@@ -144,10 +140,6 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) Mma<T>::run(o[c], vf[c], pf);
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s)
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) kcur[s][ks] = knext[s][ks];
   }
 
   float l_tot = l_part;

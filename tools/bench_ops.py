@@ -53,7 +53,8 @@ def main():
     us = timeit(lambda: ops.cast(x, yt))
     print(f"cast n={n}: {us:7.2f} us")
 
-main()
+if __name__ == "__main__":
+    main()
 
 
 def fold_costs():
@@ -80,5 +81,5 @@ def fold_costs():
     print(f"out-proj + rln                {timeit(lambda: ops.gemm(A, Wo, M, d, d, bias=b1, resid=res, out_f32=o32, ln_stat_in=stats, ln_nparts=16, ln_dim=d, rln_gamma=gam, rln_beta=bet)):7.2f} us")
 
 
-if len(sys.argv) > 3 and sys.argv[3] == 'fold':
+if __name__ == '__main__' and len(sys.argv) > 3 and sys.argv[3] == 'fold':
     fold_costs()
