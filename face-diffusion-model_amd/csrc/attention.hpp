@@ -1,6 +1,6 @@
 // Fused attention for short sequences (L <= ~1500, head_dim 64 / 128) on gfx950 MFMA.
 //
-// One workgroup (4 wavefronts) owns 16 query rows of one (clip, head).  The key tiles are dealt
+// One workgroup (4 wavefronts) owns 16 or 32 query rows of one (clip, head).  The key tiles are dealt
 // round-robin to the 4 waves, each running its own online softmax straight from L2 (K and V^T tiles
 // are a few KB per head), and the four partial (m, l, O) states are merged through LDS at the end:
 // with L <= 600 a query tile has at most 19 key tiles, so the per-wave dependent chain is <= 5 tiles
@@ -8,7 +8,10 @@
 //
 // "Swapped" formulation so that nothing has to be transposed between the two products:
 //   S^T[key][query] = K * Q^T      A-port rows = keys,   B-port cols = queries
-//   O^T[e][query]   = V^T * P^T    A-port rows = e (V^T is stored [hd][Lpad]), B-port = P^T
+//   O^T[e][query]   = V^T * P^T    A-port rows = e, B-port = P^T
+// K and V arrive "fragment-packed" (include/fdm_hip.h, fdm_attn_args; written by the QKV GEMM's epilogue):
+// each A-port fragment of a key tile is one contiguous 1 KB run, so every fragment load is a single fully
+// coalesced request (measured: the 16-rows x 64 B gathers of a row-major K cost ~30 % of the kernel).
 // The accumulator of the first product has query on the lane (lane & 15) and keys in the 4
 // registers x 4 lane groups, which is exactly the B-port fragment of the second product; the
 // softmax statistics of a query are therefore lane-local plus two cross-group shuffles
@@ -26,133 +29,189 @@
 namespace fdm {
 
 // accurate expf on the fp32 (parity) path, hardware exp2 on the bf16 (throughput) path
+// (bf16 callers pre-multiply the exponent by log2(e))
 template <typename T> __device__ __forceinline__ float fexp(float x) {
   if constexpr (sizeof(T) == 4) return expf(x);
-  else return __expf(x);
+  else return __builtin_amdgcn_exp2f(x);
 }
 
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
+template <typename T, int HD, int QS, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
+  // QS = 16-query sub-tiles per workgroup (1 or 2).  With QS = 2 every K / V^T fragment fetched from L2 feeds
+  // two S^T and two O^T products: the kernel is bound by L2 -> register fragment traffic, which this halves.
   constexpr int EPC = 16 / (int)sizeof(T);     // elements per 16 B fragment chunk
   constexpr int NKS = HD / (4 * EPC);          // MFMA k-steps over the head dim
   constexpr int KT = 4 * EPC;                  // keys per tile (bf16 32, fp32 16)
   constexpr int NSUB = KT / 16;                // 16-key sub-tiles per tile
   constexpr int NC = HD / 16;                  // 16-row chunks of O^T
+  constexpr int BQ = 16 * QS;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, r16 = lane & 15;
-  const int qt = blockIdx.x;
   const int h = blockIdx.y, b = blockIdx.z;
   const int L = p.L;
-  const int q0 = qt * 16;
-  __shared__ __attribute__((aligned(16))) float part_o[4][16][HD];
-  __shared__ float part_m[4][16], part_l[4][16];
+  const int q0 = blockIdx.x * BQ;
+  __shared__ __attribute__((aligned(16))) float part_o[4][BQ][HD];
+  __shared__ float part_m[4][BQ], part_l[4][BQ];
 
   const T* Q = (const T*)p.Q + (size_t)b * L * p.ldq + (size_t)h * HD;
-  const T* K = (const T*)p.K + (size_t)b * L * p.ldk + (size_t)h * HD;
-  const T* Vt = (const T*)p.Vt + (size_t)(b * p.H + h) * HD * p.Lpad;
+  const T* Kp = (const T*)p.Kp + (size_t)(b * p.H + h) * HD * p.Lpad + (size_t)lane * EPC;
+  const T* Vp = (const T*)p.Vp + (size_t)(b * p.H + h) * HD * p.Lpad + (size_t)lane * EPC;
 
-  const int qi = q0 + r16;                 // this lane's query index
-  const int qrow = min(qi, L - 1);
-  u32x4 qf[NKS];
+  int qi[QS];                              // this lane's query index in each sub-tile
+  u32x4 qf[QS][NKS];
+  f32x4 o[QS][NC];
+  float m_run[QS], l_part[QS];
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks)
-    qf[ks] = *(const u32x4*)(Q + (size_t)qrow * p.ldq + (ks * 4 + g) * EPC);
-
-  f32x4 o[NC];
+  for (int u = 0; u < QS; ++u) {
+    qi[u] = q0 + 16 * u + r16;
+    const int qrow = min(qi[u], L - 1);
 #pragma unroll
-  for (int c = 0; c < NC; ++c) o[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_part = 0.f;
+    for (int ks = 0; ks < NKS; ++ks) qf[u][ks] = *(const u32x4*)(Q + (size_t)qrow * p.ldq + (ks * 4 + g) * EPC);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) o[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    m_run[u] = -INFINITY;
+    l_part[u] = 0.f;
+  }
 
-  const float slope = p.slopes ? p.slopes[h] : 0.f;
-  const int kend = p.causal ? min(q0 + 16, L) : L;     // keys [0, kend) can be visible to this tile
+  // bf16 path: softmax in the log2 domain (scale and slope carry log2(e); v_exp_f32 is a bare exp2)
+  constexpr float LG = (sizeof(T) == 2) ? 1.4426950408889634f : 1.f;
+  const float sc_mul = p.scale * LG;
+  const float slope = p.slopes ? p.slopes[h] * LG : 0.f;
+  const float inv_period = 1.f / (float)p.period;
+  const bool fastbias = !p.slopes || p.period >= 8;
+  const int goff = (NSUB == 2 ? 8 : 4) * g;
+  const int kend = p.causal ? min(q0 + BQ, L) : L;     // keys [0, kend) can be visible to this workgroup
   const int ntiles = (kend + KT - 1) / KT;
 
   // Measured: software prefetch of the next tile's fragments (register double buffers, copy or ping-pong) is
-  // SLOWER here (9.1 / 10.4 us vs 8.4 us at cfg2): the extra 64 VGPRs cost residency, and residency is what hides
-  // the L2 round trips of these short per-wave chains.  So each tile simply loads its fragments and uses them.
-  const float inv_period = 1.f / (float)p.period;
-
+  // SLOWER here: the extra VGPRs cost residency, and residency is what hides the L2 round trips of these
+  // short per-wave chains.  So each tile simply loads its fragments and uses them.
   for (int kt = wave; kt < ntiles; kt += 4) {
     const int kbase = kt * KT;
+    // fragment-packed K / V: every operand fragment of this key tile is one contiguous 1 KB run
     u32x4 kcur[NSUB][NKS];
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-      // key fed by A-port row r16 of sub-tile s
-      const int krow = (NSUB == 2) ? (kbase + 8 * (r16 >> 2) + 4 * s + (r16 & 3)) : (kbase + r16);
-      const T* kp = K + (size_t)min(krow, L - 1) * p.ldk;
+    for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) kcur[s][ks] = *(const u32x4*)(kp + (ks * 4 + g) * EPC);
-    }
+      for (int ks = 0; ks < NKS; ++ks) {
+        if (DBG == 2) kcur[s][ks] = u32x4{(unsigned)kt, 1u, 2u, (unsigned)lane};
+        else kcur[s][ks] = *(const u32x4*)(Kp + (size_t)((kt * NSUB + s) * NKS + ks) * (64 * EPC));
+      }
     u32x4 vf[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) vf[c] = *(const u32x4*)(Vt + (size_t)(c * 16 + r16) * p.Lpad + kbase + g * EPC);
-    f32x4 sc[NSUB];
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s) {
-      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) Mma<T>::run(a, kcur[s][ks], qf[ks]);
-      sc[s] = a;
-    }
-    // scores -> scaled, biased, masked; this lane holds keys kbase + (NSUB==2 ? 8g+4s+r : 4g+r)
-    float mx = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kj = kbase + ((NSUB == 2) ? (8 * g + 4 * s + r) : (4 * g + r));
-        float v = sc[s][r] * p.scale;
-        // floor((qi - kj) / period) without an integer divide: (n + 0.5) / period never rounds across an integer
-        if (p.slopes) v -= slope * floorf(((float)(qi - kj) + 0.5f) * inv_period);
-        const bool masked = (kj >= L) || (p.causal && kj > qi);
-        v = masked ? -INFINITY : v;
-        sc[s][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // m_new is finite: key 0 is visible to every query in tile 0 (causal) / every key < L (non-causal)
-    const float alpha = fexp<T>(m_run - m_new);
-    float psum = 0.f;
-#pragma unroll
-    for (int s = 0; s < NSUB; ++s)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float e = fexp<T>(sc[s][r] - m_new);
-        sc[s][r] = e;
-        psum += e;
-      }
-    l_part = l_part * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) o[c] *= alpha;
-
-    // P^T fragment for the B port
-    u32x4 pf;
-    if constexpr (sizeof(T) == 2) {
-      bf16x8 pb = {(bf16)sc[0][0], (bf16)sc[0][1], (bf16)sc[0][2], (bf16)sc[0][3],
-                   (bf16)sc[NSUB - 1][0], (bf16)sc[NSUB - 1][1], (bf16)sc[NSUB - 1][2], (bf16)sc[NSUB - 1][3]};
-      pf = __builtin_bit_cast(u32x4, pb);
-    } else {
-      pf = __builtin_bit_cast(u32x4, sc[0]);
+    for (int c = 0; c < NC; ++c) {
+      if (DBG == 2) vf[c] = u32x4{(unsigned)kt, 1u, 2u, (unsigned)lane};
+      else vf[c] = *(const u32x4*)(Vp + (size_t)(kt * NC + c) * (64 * EPC));
     }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) Mma<T>::run(o[c], vf[c], pf);
+    for (int u = 0; u < QS; ++u) {
+      // a causal sub-tile whose last query precedes this key tile sees none of it (wave-uniform skip);
+      // it also guarantees every processed tile starts at a key visible to all 16 queries (finite row maxima)
+      if (p.causal && kbase > q0 + 16 * u + 15) continue;
+      f32x4 sc[NSUB];
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) Mma<T>::run(a, kcur[s][ks], qf[u][ks]);
+        sc[s] = a;
+      }
+      // scores -> scaled, biased, masked.  This lane holds keys kbase + goff + j with j = 4s + r (j < 8), so with
+      // D = qi - (kbase + goff):  floor((qi - kj) / period) = floor(D / period) - (j > D mod period)   (period >= 8)
+      // -> one compare/select/fma per score instead of an int->float convert, floor and two multiplies.
+      const int D = qi[u] - kbase - goff;
+      float b0 = 0.f, b1 = 0.f;
+      int rem = 1 << 30;
+      if (p.slopes) {
+        const float f0 = floorf(((float)D + 0.5f) * inv_period);     // (n + 0.5) / period never rounds across an integer
+        rem = D - (int)f0 * p.period;
+        b0 = slope * f0;
+        b1 = b0 - slope;
+      }
+      // only tiles that straddle the causal diagonal or the end of the sequence need the mask
+      const bool edge = (kbase + KT > L) || (p.causal && kbase + KT - 1 > q0 + 16 * u);
+      float mx = -INFINITY;
+      if (fastbias) {
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 4 * s + r;
+            sc[s][r] = sc[s][r] * sc_mul - ((j > rem) ? b1 : b0);
+          }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = 4 * s + r;
+            float v = sc[s][r] * sc_mul;
+            if (p.slopes) v -= slope * floorf(((float)(D - j) + 0.5f) * inv_period);
+            sc[s][r] = v;
+          }
+      }
+      if (edge) {
+        const int jmax = min(p.causal ? D : (1 << 30), L - 1 - kbase - goff);     // largest visible j of this lane
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sc[s][r] = (4 * s + r > jmax) ? -INFINITY : sc[s][r];
+      }
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[s][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[u], mx);
+      const float alpha = fexp<T>(m_run[u] - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = fexp<T>(sc[s][r] - m_new);
+          sc[s][r] = e;
+          psum += e;
+        }
+      l_part[u] = l_part[u] * alpha + psum;
+      m_run[u] = m_new;
+      // the running maximum usually stops moving after the first tiles: skip the (AGPR round-trip) rescale then
+      if (__any(alpha != 1.f)) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[u][c] *= alpha;
+      }
+      // P^T fragment for the B port
+      u32x4 pf;
+      if constexpr (sizeof(T) == 2) {
+        bf16x8 pb = {(bf16)sc[0][0], (bf16)sc[0][1], (bf16)sc[0][2], (bf16)sc[0][3],
+                     (bf16)sc[NSUB - 1][0], (bf16)sc[NSUB - 1][1], (bf16)sc[NSUB - 1][2], (bf16)sc[NSUB - 1][3]};
+        pf = __builtin_bit_cast(u32x4, pb);
+      } else {
+        pf = __builtin_bit_cast(u32x4, sc[0]);
+      }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) Mma<T>::run(o[u][c], vf[c], pf);
+    }
   }
 
-  float l_tot = l_part;
-  l_tot += __shfl_xor(l_tot, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
   // ---- merge the four waves' partial states ----
-  if (g == 0) { part_m[wave][r16] = m_run; part_l[wave][r16] = l_tot; }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) *(f32x4*)&part_o[wave][r16][c * 16 + 4 * g] = o[c];
+  for (int u = 0; u < QS; ++u) {
+    float l_tot = l_part[u];
+    l_tot += __shfl_xor(l_tot, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    if (g == 0) { part_m[wave][16 * u + r16] = m_run[u]; part_l[wave][16 * u + r16] = l_tot; }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) *(f32x4*)&part_o[wave][16 * u + r16][c * 16 + 4 * g] = o[u][c];
+  }
   __syncthreads();
   {
-    const int q = threadIdx.x >> 4;                  // 16 threads per query row
-    const int e0 = (threadIdx.x & 15) * (HD / 16);   // HD/16 consecutive head-dim elements per thread
+    constexpr int TPQ = 256 / BQ;                    // threads per query row (16 or 8)
+    constexpr int EPT = HD / TPQ;                    // consecutive head-dim elements per thread (multiple of 4)
+    const int q = threadIdx.x / TPQ;
+    const int e0 = (threadIdx.x % TPQ) * EPT;
     const int qq = q0 + q;
     float mw[4], ms = -INFINITY;
 #pragma unroll
@@ -164,7 +223,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
     if (qq < L) {
       T* op = (T*)p.O + ((size_t)b * L + qq) * p.ldo + (size_t)h * HD + e0;
 #pragma unroll
-      for (int j = 0; j < HD / 16; j += 4) {
+      for (int j = 0; j < EPT; j += 4) {
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) v += *(const f32x4*)&part_o[w][q][e0 + j] * sw[w];
@@ -181,18 +240,59 @@ __global__ __launch_bounds__(256) void attn_kernel(const fdm_attn_args p) {
   }
 }
 
-static hipError_t attn_launch(const fdm_attn_args& a, hipStream_t s) {
-  dim3 grid((a.L + 15) / 16, a.H, a.B);
-  dim3 block(256);
-  if (a.dtype == FDM_BF16) {
-    if (a.hd == 256) hipLaunchKernelGGL((attn_kernel<bf16, 256>), grid, block, 0, s, a);
-    else if (a.hd == 128) hipLaunchKernelGGL((attn_kernel<bf16, 128>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<bf16, 64>), grid, block, 0, s, a);
-  } else {
-    if (a.hd == 256) hipLaunchKernelGGL((attn_kernel<float, 256>), grid, block, 0, s, a);
-    else if (a.hd == 128) hipLaunchKernelGGL((attn_kernel<float, 128>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((attn_kernel<float, 64>), grid, block, 0, s, a);
+template <typename T, int HD>
+static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
+  // two query sub-tiles per workgroup once the sequence is long enough that halving the K / V traffic matters more
+  // than the number of workgroups; head_dim 256 keeps one (register budget)
+  static const int dbg = getenv("FDM_ATTN_DBG") ? atoi(getenv("FDM_ATTN_DBG")) : 0;
+  static const int qs2 = getenv("FDM_ATTN_QS2") ? atoi(getenv("FDM_ATTN_QS2")) : 384;
+  if (HD == 128 && sizeof(T) == 2 && dbg) {
+    dim3 grid((a.L + 15) / 16, a.H, a.B);
+    hipLaunchKernelGGL((attn_kernel<T, HD, 1, (HD == 128 && sizeof(T) == 2) ? 2 : 0>), grid, dim3(256), 0, s, a);
+    return;
   }
+  if (HD <= 128 && a.L >= qs2) {
+    dim3 grid((a.L + 31) / 32, a.H, a.B);
+    hipLaunchKernelGGL((attn_kernel<T, HD, (HD <= 128 ? 2 : 1)>), grid, dim3(256), 0, s, a);
+  } else {
+    dim3 grid((a.L + 15) / 16, a.H, a.B);
+    hipLaunchKernelGGL((attn_kernel<T, HD, 1>), grid, dim3(256), 0, s, a);
+  }
+}
+
+static hipError_t attn_launch(const fdm_attn_args& a, hipStream_t s) {
+  if (a.dtype == FDM_BF16) {
+    if (a.hd == 256) attn_launch_t<bf16, 256>(a, s);
+    else if (a.hd == 128) attn_launch_t<bf16, 128>(a, s);
+    else attn_launch_t<bf16, 64>(a, s);
+  } else {
+    if (a.hd == 256) attn_launch_t<float, 256>(a, s);
+    else if (a.hd == 128) attn_launch_t<float, 128>(a, s);
+    else attn_launch_t<float, 64>(a, s);
+  }
+  return hipGetLastError();
+}
+
+// row-major K, V -> fragment-packed (for C-ABI users whose projections do not come from fdm_op_gemm, and for tests)
+template <typename T>
+__global__ void pack_kv_kernel(const T* K, long long ldk, const T* V, long long ldv, T* Kp, T* Vp, int B, int H, int L, int Lpad, int hd) {
+  const size_t n = (size_t)B * L * H * hd;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int e = (int)(i % hd);
+    const int h = (int)((i / hd) % H);
+    const size_t row = i / ((size_t)hd * H);
+    const int b = (int)(row / L), l = (int)(row % L);
+    const size_t blk = (size_t)(b * H + h) * Lpad * hd;
+    Kp[blk + kp_offset<T>(l, e, hd)] = K[row * ldk + (size_t)h * hd + e];
+    Vp[blk + vp_offset<T>(l, e, hd)] = V[row * ldv + (size_t)h * hd + e];
+  }
+}
+template <typename T>
+static hipError_t pack_kv_launch(const void* K, long long ldk, const void* V, long long ldv, void* Kp, void* Vp,
+                                 int B, int H, int L, int Lpad, int hd, hipStream_t s) {
+  const size_t n = (size_t)B * L * H * hd;
+  const int blocks = (int)min((size_t)4096, (n + 255) / 256);
+  hipLaunchKernelGGL(pack_kv_kernel<T>, dim3(blocks), dim3(256), 0, s, (const T*)K, ldk, (const T*)V, ldv, (T*)Kp, (T*)Vp, B, H, L, Lpad, hd);
   return hipGetLastError();
 }
 

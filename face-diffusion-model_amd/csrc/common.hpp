@@ -64,4 +64,21 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+
+// Element offsets inside one (clip, head) block of the fragment-packed K / V buffers (include/fdm_hip.h, fdm_attn_args).
+template <typename T> __device__ __forceinline__ size_t kp_offset(int l, int e, int hd) {
+  constexpr int EPC = 16 / (int)sizeof(T), KT = 4 * EPC, NSUB = KT / 16;
+  const int NKS = hd / (4 * EPC);
+  const int kt = l / KT, w = l % KT;
+  const int s = (NSUB == 2) ? ((w >> 2) & 1) : 0;
+  const int r = (NSUB == 2) ? (((w >> 3) << 2) | (w & 3)) : w;
+  const int ch = e / EPC;
+  return ((size_t)((((kt * NSUB + s) * NKS + (ch >> 2)) * 4 + (ch & 3)) * 16 + r)) * EPC + (e % EPC);
+}
+template <typename T> __device__ __forceinline__ size_t vp_offset(int l, int e, int hd) {
+  constexpr int EPC = 16 / (int)sizeof(T), KT = 4 * EPC;
+  const int kt = l / KT, w = l % KT;
+  return ((size_t)(((kt * (hd >> 4) + (e >> 4)) * 4 + w / EPC) * 16 + (e & 15))) * EPC + (w % EPC);
+}
+
 }  // namespace fdm

@@ -96,9 +96,15 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (a->K % bk) return fail(FDM_ERR_SHAPE, "gemm: K=%d not a multiple of %d", a->K, bk);
   if (a->lda % epc || a->ldw % epc || !aligned16(a->A) || !aligned16(a->W)) return fail(FDM_ERR_ARG, "gemm: operands need 16-byte aligned rows");
   if (a->a_batch_stride % epc || a->w_batch_stride % epc) return fail(FDM_ERR_ARG, "gemm: batch strides need 16-byte alignment");
-  if (!a->out_f32 && !a->out_t && !a->out_vt) return fail(FDM_ERR_ARG, "gemm: no output");
-  if (a->out_vt && (a->vt_hd <= 0 || a->vt_L <= 0 || a->vt_Lpad < a->vt_L || a->vt_col0 < 0 || (a->N - a->vt_col0) % a->vt_hd || a->vt_col0 % 4))
-    return fail(FDM_ERR_SHAPE, "gemm: bad V^T tail");
+  if (!a->out_f32 && !a->out_t && !a->out_vp && !a->out_kp) return fail(FDM_ERR_ARG, "gemm: no output");
+  if (a->out_kp || a->out_vp) {
+    const int hi = a->out_vp ? a->vp_col0 : a->N;
+    if (a->kv_hd <= 0 || a->kv_hd % 16 || a->kv_L <= 0 || a->kv_Lpad < a->kv_L || a->kv_Lpad % 32 || a->M % a->kv_L)
+      return fail(FDM_ERR_SHAPE, "gemm: bad packed K/V geometry (hd %d, L %d, Lpad %d)", a->kv_hd, a->kv_L, a->kv_Lpad);
+    if (a->out_vp && (a->vp_col0 < 0 || a->vp_col0 % 4 || (a->N - a->vp_col0) % a->kv_hd)) return fail(FDM_ERR_SHAPE, "gemm: bad packed V column range");
+    if (a->out_kp && (a->kp_col0 < 0 || a->kp_col0 % 4 || hi < a->kp_col0 || (hi - a->kp_col0) % a->kv_hd)) return fail(FDM_ERR_SHAPE, "gemm: bad packed K column range");
+    if (!aligned16(a->out_kp) || !aligned16(a->out_vp)) return fail(FDM_ERR_ARG, "gemm: packed K/V buffers must be 16-byte aligned");
+  }
   if (a->bias && !aligned16(a->bias)) return fail(FDM_ERR_ARG, "gemm: bias must be 16-byte aligned");
   if (a->ln_stat_in && (a->ln_nparts <= 0 || a->ln_dim <= 0)) return fail(FDM_ERR_ARG, "gemm: ln_stat_in needs ln_nparts and ln_dim");
   if ((a->ln_colsum || a->rln_gamma) && !a->ln_stat_in) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding needs ln_stat_in");
@@ -109,16 +115,27 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
 }
 
 int fdm_op_attention(const fdm_attn_args* a, void* stream) {
-  if (!a || !a->Q || !a->K || !a->Vt || !a->O) return fail(FDM_ERR_ARG, "attention: null operand");
+  if (!a || !a->Q || !a->Kp || !a->Vp || !a->O) return fail(FDM_ERR_ARG, "attention: null operand");
   if (a->hd != 64 && a->hd != 128 && a->hd != 256) return fail(FDM_ERR_SHAPE, "attention: head_dim %d unsupported (64, 128, 256)", a->hd);
   if (a->B <= 0 || a->H <= 0 || a->L <= 0) return fail(FDM_ERR_SHAPE, "attention: B,H,L must be positive");
   if (a->Lpad < a->L || a->Lpad % 32) return fail(FDM_ERR_SHAPE, "attention: Lpad=%d must be a multiple of 32 >= L", a->Lpad);
   const int epc = a->dtype == FDM_BF16 ? 8 : 4;
-  if (a->ldq % epc || a->ldk % epc || a->ldo % 4 || !aligned16(a->Q) || !aligned16(a->K) || !aligned16(a->Vt) || !aligned16(a->O))
+  if (a->ldq % epc || a->ldo % 4 || !aligned16(a->Q) || !aligned16(a->Kp) || !aligned16(a->Vp) || !aligned16(a->O))
     return fail(FDM_ERR_ARG, "attention: operands need 16-byte aligned rows");
   if (a->slopes && a->period <= 0) return fail(FDM_ERR_ARG, "attention: period must be positive");
   fdm_attn_args c = *a;
   return submit([c](hipStream_t s) { return fdm::attn_launch(c, s); }, stream, "attention");
+}
+
+int fdm_op_pack_kv(const void* K, long long ldk, const void* V, long long ldv, void* Kp, void* Vp,
+                   int B, int H, int L, int Lpad, int hd, int dtype, void* stream) {
+  if (!K || !V || !Kp || !Vp) return fail(FDM_ERR_ARG, "pack_kv: null operand");
+  if (B <= 0 || H <= 0 || L <= 0 || Lpad < L || Lpad % 32 || hd <= 0 || hd % 16) return fail(FDM_ERR_SHAPE, "pack_kv: bad geometry");
+  if (dtype != FDM_F32 && dtype != FDM_BF16) return fail(FDM_ERR_ARG, "pack_kv: bad dtype %d", dtype);
+  return submit([=](hipStream_t s) {
+    return dtype == FDM_BF16 ? fdm::pack_kv_launch<fdm::bf16>(K, ldk, V, ldv, Kp, Vp, B, H, L, Lpad, hd, s)
+                             : fdm::pack_kv_launch<float>(K, ldk, V, ldv, Kp, Vp, B, H, L, Lpad, hd, s);
+  }, stream, "pack_kv");
 }
 
 int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {

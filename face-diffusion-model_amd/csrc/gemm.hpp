@@ -60,12 +60,11 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
                                               int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   const int M = p.M, N = p.N;
-  // Whole-tile V^T fast path: stage the tile transposed in LDS ([n][m], the ring is free after the k loop) and
-  // store 16-byte runs along l.  Needs the tile to lie entirely in the V columns and clip boundaries on
-  // 16-byte multiples (L % (16 / sizeof(T)) == 0); otherwise the per-element scatter below is used.
+  // Whole-tile packed-V fast path: stage the tile transposed in LDS ([n][m], the ring is free after the k loop) and
+  // store 16-byte runs of consecutive keys (one packed chunk each).  Needs the tile to lie entirely in the V columns
+  // and clip boundaries on 16-byte multiples (L % (16 / sizeof(T)) == 0); otherwise the per-element scatter is used.
   constexpr int EPC_T = 16 / (int)sizeof(T);
-  const bool vt_tile = tile_lds && p.out_vt && n0 >= p.vt_col0 && n0 + BN <= N && (p.vt_L % EPC_T == 0) &&
-                       (p.vt_Lpad % EPC_T == 0) && (p.vt_hd % 4 == 0);
+  const bool vt_tile = tile_lds && p.out_vp && n0 >= p.vp_col0 && n0 + BN <= N && (p.kv_L % EPC_T == 0);
   T* tl = (T*)tile_lds;
   if (vt_tile) __syncthreads();      // every wave is done reading the last ring stage
   float* comb = rowstat ? rowstat + BM * 2 : nullptr;
@@ -77,7 +76,9 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   const bool vec_f32 = p.out_f32 && (p.ldo_f32 % 4 == 0) && (((uintptr_t)(p.out_f32 + ocol)) % 16 == 0);
   const bool vec_t = p.out_t && (p.ldo_t % 4 == 0) && (((uintptr_t)((T*)p.out_t + ocol)) % (4 * sizeof(T)) == 0);
   const bool vec_r = p.resid && (p.ldr % 4 == 0) && (((uintptr_t)(p.resid + ocol)) % 16 == 0);
-  const int vt_H = p.out_vt ? (N - p.vt_col0) / p.vt_hd : 0;
+  const int kv_H = p.out_vp ? (N - p.vp_col0) / p.kv_hd : 0;
+  const size_t kv_blk = (size_t)p.kv_Lpad * p.kv_hd;        // elements per (clip, head) block of the packed buffers
+  const int kcol_lo = p.out_kp ? p.kp_col0 : N, kcol_hi = p.out_kp ? (p.out_vp ? p.vp_col0 : N) : N;
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int lrow = wm * (BM / WM) + mi * 16 + r16;
@@ -86,6 +87,8 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
     const size_t rrow = p.resid_row_mod > 0 ? (size_t)(m % p.resid_row_mod) : (size_t)m;
     const float mu = use_ln ? rowstat[2 * lrow] : 0.f, rs = use_ln ? rowstat[2 * lrow + 1] : 1.f;
     float ps = 0.f, pq = 0.f;
+    int kv_b = 0, kv_l = 0;
+    if (p.out_kp || p.out_vp) { kv_b = m / p.kv_L; kv_l = m - kv_b * p.kv_L; }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
       const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * g;
@@ -141,14 +144,27 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<T>(v[j]);
         continue;
       }
-      if (p.out_vt && n >= p.vt_col0) {
-        // scatter transposed: Vt[((b*H + h)*hd + e)*Lpad + l]
-        const int b = m / p.vt_L, l = m - b * p.vt_L;
+      if (n >= kcol_lo && n < kcol_hi) {
+        // packed K: this lane's 4 columns sit inside one 16-byte chunk of key kv_l (kv_hd % 4 == 0, column ranges % 4 == 0)
+        const int cc = n - kcol_lo;
+        const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
+        const int KH = (kcol_hi - kcol_lo) / p.kv_hd;
+        T* dst = (T*)p.out_kp + (size_t)(kv_b * KH + h) * kv_blk + kp_offset<T>(kv_l, e, p.kv_hd);
+        if constexpr (sizeof(T) == 4) {
+          *(f32x4*)dst = v;
+        } else {
+          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+          *(bf16x4*)dst = o;
+        }
+        continue;
+      }
+      if (p.out_vp && n >= p.vp_col0) {
         for (int j = 0; j < 4; ++j) {
           if (n + j >= N) break;
-          const int cc = n + j - p.vt_col0;
-          const int h = cc / p.vt_hd, e = cc - h * p.vt_hd;
-          ((T*)p.out_vt)[((size_t)(b * vt_H + h) * p.vt_hd + e) * p.vt_Lpad + l] = from_f32<T>(v[j]);
+          const int cc = n + j - p.vp_col0;
+          const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
+          ((T*)p.out_vp)[(size_t)(kv_b * kv_H + h) * kv_blk + vp_offset<T>(kv_l, e, p.kv_hd)] = from_f32<T>(v[j]);
         }
         continue;
       }
@@ -190,10 +206,10 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       const int nl = c / CPR, ml = (c % CPR) * EPC_T;
       const int m = m0 + ml;
       if (m >= M) continue;                               // M is a multiple of L, L of EPC_T: chunks are all-in or all-out
-      const int b = m / p.vt_L, l = m - b * p.vt_L;
-      const int cc = n0 + nl - p.vt_col0;
-      const int h = cc / p.vt_hd, e = cc - h * p.vt_hd;
-      *(u32x4*)((T*)p.out_vt + ((size_t)(b * vt_H + h) * p.vt_hd + e) * p.vt_Lpad + l) = *(const u32x4*)(tl + nl * BM + ml);
+      const int b = m / p.kv_L, l = m - b * p.kv_L;
+      const int cc = n0 + nl - p.vp_col0;
+      const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
+      *(u32x4*)((T*)p.out_vp + (size_t)(b * kv_H + h) * kv_blk + vp_offset<T>(l, e, p.kv_hd)) = *(const u32x4*)(tl + nl * BM + ml);
     }
   }
   if (do_stat) {

@@ -20,13 +20,14 @@ class GemmArgs(C.Structure):
                 ("resid", vp), ("ldr", ll), ("resid_row_mod", ci),
                 ("out_f32", vp), ("ldo_f32", ll), ("out_t", vp), ("ldo_t", ll),
                 ("out_batch_stride", ll),
-                ("out_vt", vp), ("vt_col0", ci), ("vt_L", ci), ("vt_Lpad", ci), ("vt_hd", ci),
+                ("out_kp", vp), ("kp_col0", ci), ("out_vp", vp), ("vp_col0", ci),
+                ("kv_L", ci), ("kv_Lpad", ci), ("kv_hd", ci),
                 ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
                 ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp)]
 
 
 class AttnArgs(C.Structure):
-    _fields_ = [("Q", vp), ("ldq", ll), ("K", vp), ("ldk", ll), ("Vt", vp), ("Lpad", ci),
+    _fields_ = [("Q", vp), ("ldq", ll), ("Kp", vp), ("Vp", vp), ("Lpad", ci),
                 ("O", vp), ("ldo", ll), ("B", ci), ("H", ci), ("L", ci), ("hd", ci), ("dtype", ci),
                 ("scale", cf), ("causal", ci), ("slopes", vp), ("period", ci)]
 
@@ -53,6 +54,7 @@ SYMBOLS = {
     "fdm_device_ok": (ci, []),
     "fdm_op_gemm": (ci, [C.POINTER(GemmArgs), vp]),
     "fdm_op_attention": (ci, [C.POINTER(AttnArgs), vp]),
+    "fdm_op_pack_kv": (ci, [vp, ll, vp, ll, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "fdm_op_layernorm": (ci, [C.POINTER(LnArgs), vp]),
     "fdm_op_sched_step": (ci, [C.POINTER(SchedArgs), vp]),
     "fdm_op_cast": (ci, [vp, vp, ll, ci, vp]),

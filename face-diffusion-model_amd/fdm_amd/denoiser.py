@@ -189,7 +189,7 @@ class DenoiserPlan:
         p, dv, d = self.p, self.device, self.p.d
         R, td = self.R, self.td
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dv, dtype=dt)
-        self.Lpad = (self.L + 31) // 32 * 32
+        self.Lpad = ops.kv_pad(self.L)
         ws = dict(h=z(R, d), h2=z(R, d), x1=z(R, d), x0=z(R, d), x=z(self.M, d))
         if self.dtype == BF16:
             ws.update(xt=z(self.M, d, dt=td), ht=z(R, d, dt=td), h2t=z(R, d, dt=td))
@@ -197,8 +197,10 @@ class DenoiserPlan:
             ws.update(xt=ws["x"], ht=ws["h"], h2t=ws["h2"])
         if self.fuse_ln3:
             ws.update(x2=z(R, d), x2t=z(R, d, dt=td), stats=z(self.chains, d // 64, self.Rc, 2))
-        ws.update(qkv=z(R, 3 * d, dt=td), ctx=z(R, d, dt=td), u=z(R, p.ffn, dt=td),
-                  vt=z(self.B * self.rep * p.n_head, p.head_dim, self.Lpad, dt=td))
+        # q: row-major queries; kp / vp: fragment-packed keys / values written by the QKV GEMM's epilogue (zeroed: pad keys)
+        ws.update(q=z(R, d, dt=td), ctx=z(R, d, dt=td), u=z(R, p.ffn, dt=td),
+                  kp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=td),
+                  vp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=td))
         self.ws = ws
         self.step = torch.zeros(self.chains, dtype=torch.int32, device=dv)      # one device-side step counter per chain
         self.tseq = torch.zeros(1024, dtype=torch.int32, device=dv)
@@ -220,7 +222,9 @@ class DenoiserPlan:
                      out_t=ws["ht"][o:] if both else None,
                      incr_counter=step if r == 0 else None)      # first kernel of the step: step counter += 1
         BBc = Bc * self.rep
-        vt = ws["vt"][c * BBc * p.n_head:]
+        kp, vp = ws["kp"][c * BBc * p.n_head:], ws["vp"][c * BBc * p.n_head:]
+        kv = dict(out_t=ws["q"][rb:], ldo_t=d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=self.Lpad,
+                  kv_hd=p.head_dim)
         fuse = self.fuse_ln3
         st = ws["stats"][c] if fuse else None
         np_, eps = d // 64, 1e-5
@@ -228,14 +232,12 @@ class DenoiserPlan:
             pre = f"transformer_decoder.layers.{l}."
             f = self.fold.get(l) if fuse else None
             if f is None:      # layer input h (fp32) / ht (operand copy) are materialised
-                ops.gemm(ws["ht"][rb:], wt[pre + "self_attn.in_proj_weight"], Rc, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"],
-                         out_t=ws["qkv"][rb:], ldo_t=3 * d, out_vt=vt, vt_col0=2 * d, vt_L=L, vt_Lpad=self.Lpad, vt_hd=p.head_dim)
+                ops.gemm(ws["ht"][rb:], wt[pre + "self_attn.in_proj_weight"], Rc, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"], **kv)
             else:              # layer input = LN3(x2) of the previous layer, never materialised
-                ops.gemm(ws["x2t"][rb:], f["w"], Rc, 3 * d, d, bias=f["bias"], out_t=ws["qkv"][rb:], ldo_t=3 * d, out_vt=vt,
-                         vt_col0=2 * d, vt_L=L, vt_Lpad=self.Lpad, vt_hd=p.head_dim,
+                ops.gemm(ws["x2t"][rb:], f["w"], Rc, 3 * d, d, bias=f["bias"], **kv,
                          ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
-            ops.attention(ws["qkv"][rb:], ws["qkv"][rb:, d:], vt, ws["ctx"][rb:], B=BBc, H=p.n_head, L=L, hd=p.head_dim,
-                          ldq=3 * d, ldk=3 * d, ldo=d, Lpad=self.Lpad, scale=1.0 / math.sqrt(p.head_dim), causal=True,
+            ops.attention(ws["q"][rb:], kp, vp, ws["ctx"][rb:], B=BBc, H=p.n_head, L=L, hd=p.head_dim,
+                          ldq=d, ldo=d, Lpad=self.Lpad, scale=1.0 / math.sqrt(p.head_dim), causal=True,
                           slopes=self.slopes, period=p.period)
             if f is None:
                 ops.gemm(ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],

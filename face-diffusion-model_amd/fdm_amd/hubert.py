@@ -192,19 +192,18 @@ class HubertPlan:
                          out_f32=h2[b * N:], ldo_f32=D, out_bs=dg)
             h = h2
             # --- encoder layers ---
-            Lpad = (N + 31) // 32 * 32
             xt = z(M, D, dtp=td)
-            qkv = z(M, 3 * D, dtp=td)
-            vt = torch.zeros(B * N_HEAD, HD, Lpad, device=dv, dtype=td)
+            q = z(M, D, dtp=td)
+            kp, vp, Lpad = ops.kv_buffers(B, N_HEAD, N, HD, td, dv)
+            kv = dict(out_t=q, ldo_t=D, out_kp=kp, kp_col0=D, out_vp=vp, vp_col0=2 * D, kv_L=N, kv_Lpad=Lpad, kv_hd=HD)
             ctx = z(M, D, dtp=td)
             u = z(M, FFN, dtp=td)
             hb = z(M, D)
             if cfg.stable_ln:      # pre-LN layers, final LayerNorm (HubertEncoderStableLayerNorm)
                 for ly in self.layers:
                     ops.layernorm(h, ly["ln1"][0], ly["ln1"][1], M, D, y_t=xt, dtype=dt)
-                    ops.gemm(xt, ly["wqkv"], M, 3 * D, D, bias=ly["bqkv"], out_t=qkv, ldo_t=3 * D, out_vt=vt, vt_col0=2 * D,
-                             vt_L=N, vt_Lpad=Lpad, vt_hd=HD)
-                    ops.attention(qkv, qkv[:, D:], vt, ctx, B=B, H=N_HEAD, L=N, hd=HD, ldq=3 * D, ldk=3 * D, ldo=D, Lpad=Lpad,
+                    ops.gemm(xt, ly["wqkv"], M, 3 * D, D, bias=ly["bqkv"], **kv)
+                    ops.attention(q, kp, vp, ctx, B=B, H=N_HEAD, L=N, hd=HD, ldq=D, ldo=D, Lpad=Lpad,
                                   scale=HD ** -0.5, causal=False)
                     ops.gemm(ctx, ly["wo"], M, D, D, bias=ly["bo"], resid=h, out_f32=hb)
                     ops.layernorm(hb, ly["ln2"][0], ly["ln2"][1], M, D, y_t=xt, dtype=dt)
@@ -219,9 +218,8 @@ class HubertPlan:
                 ops.layernorm(h, self.final_ln[0], self.final_ln[1], M, D, y_f32=hb, y_t=ht, dtype=dt)
                 for ly in self.layers:
                     a_in = xt if both else hb
-                    ops.gemm(a_in, ly["wqkv"], M, 3 * D, D, bias=ly["bqkv"], out_t=qkv, ldo_t=3 * D, out_vt=vt, vt_col0=2 * D,
-                             vt_L=N, vt_Lpad=Lpad, vt_hd=HD)
-                    ops.attention(qkv, qkv[:, D:], vt, ctx, B=B, H=N_HEAD, L=N, hd=HD, ldq=3 * D, ldk=3 * D, ldo=D, Lpad=Lpad,
+                    ops.gemm(a_in, ly["wqkv"], M, 3 * D, D, bias=ly["bqkv"], **kv)
+                    ops.attention(q, kp, vp, ctx, B=B, H=N_HEAD, L=N, hd=HD, ldq=D, ldo=D, Lpad=Lpad,
                                   scale=HD ** -0.5, causal=False)
                     ops.gemm(ctx, ly["wo"], M, D, D, bias=ly["bo"], resid=hb, out_f32=x1)
                     ops.layernorm(x1, ly["ln1"][0], ly["ln1"][1], M, D, y_f32=hb, y_t=ht, dtype=dt)

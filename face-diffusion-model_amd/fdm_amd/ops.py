@@ -38,7 +38,7 @@ def code_of(t):
 
 def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=None, ldr=None, resid_row_mod=0,
          out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
-         out_vt=None, vt_col0=0, vt_L=0, vt_Lpad=0, vt_hd=0,
+         out_kp=None, kp_col0=0, out_vp=None, vp_col0=0, kv_L=0, kv_Lpad=0, kv_hd=0,
          stat_out=None, ln_stat_in=None, ln_nparts=0, ln_dim=0, ln_eps=1e-5, ln_colsum=None, rln_gamma=None, rln_beta=None,
          incr_counter=None):
     a = GemmArgs()
@@ -52,16 +52,33 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.out_f32, a.ldo_f32 = _p(out_f32), (ldo_f32 if ldo_f32 is not None else N)
     a.out_t, a.ldo_t = _p(out_t), (ldo_t if ldo_t is not None else N)
     a.out_batch_stride = out_bs
-    a.out_vt, a.vt_col0, a.vt_L, a.vt_Lpad, a.vt_hd = _p(out_vt), vt_col0, vt_L, vt_Lpad, vt_hd
+    a.out_kp, a.kp_col0, a.out_vp, a.vp_col0 = _p(out_kp), kp_col0, _p(out_vp), vp_col0
+    a.kv_L, a.kv_Lpad, a.kv_hd = kv_L, kv_Lpad, kv_hd
     a.stat_out, a.ln_stat_in, a.ln_nparts, a.ln_dim, a.ln_eps = _p(stat_out), _p(ln_stat_in), ln_nparts, ln_dim, ln_eps
     a.ln_colsum, a.rln_gamma, a.rln_beta = _p(ln_colsum), _p(rln_gamma), _p(rln_beta)
     a.incr_counter = _p(incr_counter)
     check(lib().fdm_op_gemm(C.byref(a), stream()))
 
 
-def attention(Q, K, Vt, O, *, B, H, L, hd, ldq, ldk, ldo, Lpad, scale, causal=False, slopes=None, period=1):
+def kv_pad(L):
+    """Padded key count of the fragment-packed K / V buffers (whole 32-key tiles)."""
+    return (L + 31) // 32 * 32
+
+
+def kv_buffers(B, H, L, hd, dtype, device):
+    """Zeroed fragment-packed K and V buffers ([B*H, Lpad*hd] each; pad keys must stay finite)."""
+    Lpad = kv_pad(L)
+    return (torch.zeros(B * H, Lpad * hd, device=device, dtype=dtype),
+            torch.zeros(B * H, Lpad * hd, device=device, dtype=dtype), Lpad)
+
+
+def pack_kv(K, V, Kp, Vp, *, B, H, L, Lpad, hd, ldk, ldv):
+    check(lib().fdm_op_pack_kv(_p(K), ldk, _p(V), ldv, _p(Kp), _p(Vp), B, H, L, Lpad, hd, code_of(K), stream()))
+
+
+def attention(Q, Kp, Vp, O, *, B, H, L, hd, ldq, ldo, Lpad, scale, causal=False, slopes=None, period=1):
     a = AttnArgs()
-    a.Q, a.ldq, a.K, a.ldk, a.Vt, a.Lpad = _p(Q), ldq, _p(K), ldk, _p(Vt), Lpad
+    a.Q, a.ldq, a.Kp, a.Vp, a.Lpad = _p(Q), ldq, _p(Kp), _p(Vp), Lpad
     a.O, a.ldo, a.B, a.H, a.L, a.hd, a.dtype = _p(O), ldo, B, H, L, hd, code_of(Q)
     a.scale, a.causal, a.slopes, a.period = scale, int(causal), _p(slopes), period
     check(lib().fdm_op_attention(C.byref(a), stream()))

@@ -80,14 +80,14 @@ class VQPlan:
         dv, td, dt, d = self.device, self.td, self.dtype, VQ_HIDDEN
         M, H, hd = B * L, VQ_HEADS, VQ_HIDDEN // VQ_HEADS
         z = lambda *s, dtp=torch.float32: torch.empty(*s, device=dv, dtype=dtp)
-        Lpad = (L + 31) // 32 * 32
-        qkv = z(M, 3 * d, dtp=td)
-        vt = torch.zeros(B * H, hd, Lpad, device=dv, dtype=td)
+        q = z(M, d, dtp=td)
+        kp, vp, Lpad = ops.kv_buffers(B, H, L, hd, td, dv)
         ctx, u, hb, a = z(M, d, dtp=td), z(M, VQ_FFN, dtp=td), z(M, d), z(M, d, dtp=td)
         for ly in layers:
             ops.layernorm(h, ly["ln1"][0], ly["ln1"][1], M, d, y_t=a, dtype=dt)
-            ops.gemm(a, ly["wqkv"], M, 3 * d, d, out_t=qkv, ldo_t=3 * d, out_vt=vt, vt_col0=2 * d, vt_L=L, vt_Lpad=Lpad, vt_hd=hd)
-            ops.attention(qkv, qkv[:, d:], vt, ctx, B=B, H=H, L=L, hd=hd, ldq=3 * d, ldk=3 * d, ldo=d, Lpad=Lpad,
+            ops.gemm(a, ly["wqkv"], M, 3 * d, d, out_t=q, ldo_t=d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d,
+                     kv_L=L, kv_Lpad=Lpad, kv_hd=hd)
+            ops.attention(q, kp, vp, ctx, B=B, H=H, L=L, hd=hd, ldq=d, ldo=d, Lpad=Lpad,
                           scale=d ** -0.5, causal=False)
             ops.gemm(ctx, ly["wo"], M, d, d, bias=ly["bo"], resid=h, out_f32=hb)
             ops.layernorm(hb, ly["ln2"][0], ly["ln2"][1], M, d, y_t=a, dtype=dt)

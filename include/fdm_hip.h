@@ -48,21 +48,25 @@ int fdm_device_ok(void);
  * models/lib/base_models.py:71-87,138-174; models/vq_vae_vocaset.py:204,243).
  * A rows may overlap (lda < K) which expresses a strided Conv1d over a channels-last signal
  * without im2col.  v = acc + bias[n]; v = act(v); v += resid[m or m % mod][n]; stores fp32
- * and/or operand-dtype copies; columns >= vt_col0 can be scattered transposed into a
- * [B*H, hd, Lpad] "V^T" buffer for the attention kernel.  K must be a multiple of 32 (fp32) /
+ * and/or operand-dtype copies.  For a fused QKV projection the K columns [kp_col0, vp_col0) and the
+ * V columns [vp_col0, N) can be written straight into the attention kernel's fragment-packed
+ * buffers (see fdm_attn_args) instead of out_t/out_f32.  K must be a multiple of 32 (fp32) /
  * 64 (bf16); A, W 16-byte aligned with lda, ldw multiples of 4 (fp32) / 8 (bf16).            */
 typedef struct fdm_gemm_args {
   const void* A; long long lda; long long a_batch_stride;
   const void* W; long long ldw; long long w_batch_stride;
   int M, N, K, batch;
-  int dtype;                      /* FDM_F32 | FDM_BF16: type of A, W, out_t, out_vt */
+  int dtype;                      /* FDM_F32 | FDM_BF16: type of A, W, out_t, out_kp, out_vp */
   const float* bias; long long bias_batch_stride;
   int act;
   const float* resid; long long ldr; int resid_row_mod;
   float* out_f32; long long ldo_f32;
   void* out_t; long long ldo_t;
   long long out_batch_stride;     /* elements, applied to out_f32, out_t and resid (column offset) */
-  void* out_vt; int vt_col0; int vt_L; int vt_Lpad; int vt_hd;
+  /* packed K / V outputs: rows are (clip b = m / kv_L, key l = m % kv_L), columns h*kv_hd + e inside each range */
+  void* out_kp; int kp_col0;
+  void* out_vp; int vp_col0;
+  int kv_L; int kv_Lpad; int kv_hd;
   /* --- LayerNorm folded into the GEMMs around it (bf16 step program; removes the norm3 launch) ---
    * producer: stat_out != NULL -> per-row partial (sum v, sum v^2) of the fp32 outputs of each 64-column
    *   group are written to stat_out[(n/64) * 2M + 2m + {0,1}] (plain stores, fixed order: deterministic).
@@ -85,12 +89,21 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
  * nn.MultiheadAttention self-attention with the causal periodic-ALiBi mask generated in-kernel
  * (models/fdm_vocaset.py:85,95-116: mask[h,i,j] = -slope_h*floor((i-j)/period), -inf for j>i);
  * non-causal for HuBERT (hd 64, scale 1/8) and the VQ decoder (hd 128, scale hidden^-0.5,
- * models/lib/base_models.py:144).  Q, K: row (b*L + l), column h*hd + e, row strides ldq/ldk.
- * Vt: [B*H, hd, Lpad] (written by fdm_op_gemm's vt tail).  O: [B*L, ldo] operand dtype.     */
+ * models/lib/base_models.py:144).  Q: row (b*L + l), column h*hd + e, row stride ldq.
+ * O: [B*L, ldo] operand dtype.
+ * Kp, Vp: "fragment-packed" keys / values, one block of Lpad*hd elements per (b, h) (Lpad a
+ * multiple of 32, pad keys must hold finite values, e.g. zeros), laid out so that every MFMA
+ * operand fragment of a key tile is ONE contiguous 1 KB run (64 lanes x 16 B):
+ *   EPC = 16 / sizeof(T) elements per chunk, key tile KT = 4*EPC keys (bf16 32, fp32 16)
+ *   Kp[ ((((kt*NSUB + s)*NKS + ks)*4 + g)*16 + r)*EPC + e%EPC ]   NSUB = KT/16, NKS = hd/(4*EPC)
+ *       key l = kt*KT + w;  bf16: s = (w>>2)&1, r = 4*(w>>3) + (w&3);  fp32: s = 0, r = w
+ *       column e: chunk e/EPC = 4*ks + g
+ *   Vp[ (((kt*(hd/16) + e/16)*4 + g)*16 + e%16)*EPC + w%EPC ]        g = w / EPC
+ * Written by fdm_op_gemm (out_kp / out_vp) or by fdm_op_pack_kv from row-major K, V.          */
 typedef struct fdm_attn_args {
   const void* Q; long long ldq;
-  const void* K; long long ldk;
-  const void* Vt; int Lpad;
+  const void* Kp;
+  const void* Vp; int Lpad;
   void* O; long long ldo;
   int B, H, L, hd;
   int dtype;
@@ -100,6 +113,9 @@ typedef struct fdm_attn_args {
   int period;
 } fdm_attn_args;
 int fdm_op_attention(const fdm_attn_args* a, void* stream);
+/* row-major K, V (row b*L + l, column h*hd + e, row strides ldk / ldv) -> the packed layouts above */
+int fdm_op_pack_kv(const void* K, long long ldk, const void* V, long long ldv, void* Kp, void* Vp,
+                   int B, int H, int L, int Lpad, int hd, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * y = act(LayerNorm(x + add_mat + add_tab[idx]) * gamma + beta), one wavefront per row

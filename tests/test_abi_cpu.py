@@ -42,7 +42,7 @@ def test_argument_validation_without_device():
     s.x0, s.x_out, s.n = 16, 16, 6
     assert l.fdm_op_sched_step(C.byref(s), None) == -2
     at = _lib.AttnArgs()
-    at.Q = at.K = at.Vt = at.O = 16
+    at.Q = at.Kp = at.Vp = at.O = 16
     at.hd = 96
     assert l.fdm_op_attention(C.byref(at), None) == -2
 

@@ -103,38 +103,81 @@ def alibi(H, L, period, slopes):
     return m.masked_fill((j > i).unsqueeze(0), float("-inf"))
 
 
+def pack_ref(k, v, Lpad, dtype):
+    """Host restatement of the fragment-packed K / V layouts (include/fdm_hip.h, fdm_attn_args).
+    k, v: [B, H, L, hd] -> two [B*H, Lpad*hd] tensors (pad keys zero)."""
+    B, H, L, hd = k.shape
+    epc = 8 if dtype == BF16 else 4
+    kt_keys = 4 * epc
+    nsub, nks = kt_keys // 16, hd // (4 * epc)
+    l = torch.arange(L).view(L, 1)
+    e = torch.arange(hd).view(1, hd)
+    kt, w = l // kt_keys, l % kt_keys
+    if nsub == 2:
+        sub, r = (w >> 2) & 1, ((w >> 3) << 2) | (w & 3)
+    else:
+        sub, r = torch.zeros_like(w), w
+    ch = e // epc
+    koff = (((((kt * nsub + sub) * nks + (ch >> 2)) * 4 + (ch & 3)) * 16 + r) * epc + e % epc).reshape(-1)
+    voff = ((((kt * (hd // 16) + (e >> 4)) * 4 + w // epc) * 16 + (e & 15)) * epc + w % epc).reshape(-1)
+    assert koff.unique().numel() == L * hd and voff.unique().numel() == L * hd
+    kp = torch.zeros(B * H, Lpad * hd, dtype=k.dtype)
+    vp = torch.zeros(B * H, Lpad * hd, dtype=v.dtype)
+    kp[:, koff] = k.reshape(B * H, L * hd)
+    vp[:, voff] = v.reshape(B * H, L * hd)
+    return kp, vp
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
-@pytest.mark.parametrize("B,H,L,hd,causal", [(1, 2, 7, 128, True), (2, 8, 100, 128, True), (4, 8, 200, 128, True),
-                                             (1, 4, 600, 128, True), (2, 16, 98, 64, False), (1, 8, 33, 128, False),
-                                             (1, 16, 498, 64, False)])
-def test_attention_via_qkv_gemm_layout(dtype, B, H, L, hd, causal):
-    """QKV produced by the GEMM (V scattered transposed), then the fused attention kernel."""
+@pytest.mark.parametrize("B,H,L,hd,causal,period", [(1, 2, 7, 128, True, 30), (2, 8, 100, 128, True, 30), (4, 8, 200, 128, True, 30),
+                                                    (1, 4, 600, 128, True, 25), (2, 16, 98, 64, False, 1), (1, 8, 33, 128, False, 1),
+                                                    (1, 16, 498, 64, False, 1), (2, 4, 75, 256, True, 25), (2, 4, 130, 128, True, 3),
+                                                    (3, 4, 384, 128, True, 30), (1, 8, 500, 64, True, 30)])
+def test_attention_via_qkv_gemm_layout(dtype, B, H, L, hd, causal, period):
+    """QKV produced by the GEMM (K and V written fragment-packed by its epilogue), then the fused attention kernel."""
     g = torch.Generator().manual_seed(L + hd)
     td = ops.tdtype(dtype)
     d = H * hd
     x = torch.randn(B * L, d, generator=g).to(td)
     Wqkv = (torch.randn(3 * d, d, generator=g) / math.sqrt(d)).to(td)
     bqkv = 0.1 * torch.randn(3 * d, generator=g)
-    Lpad = (L + 31) // 32 * 32
-    qkv_t = torch.zeros(B * L, 3 * d, device=DEV, dtype=td)
-    vt = torch.zeros(B * H, hd, Lpad, device=DEV, dtype=td)
-    ops.gemm(x.to(DEV), Wqkv.to(DEV), B * L, 3 * d, d, bias=bqkv.to(DEV), out_t=qkv_t, ldo_t=3 * d,
-             out_vt=vt, vt_col0=2 * d, vt_L=L, vt_Lpad=Lpad, vt_hd=hd)
+    q_t = torch.zeros(B * L, d, device=DEV, dtype=td)
+    kp, vp, Lpad = ops.kv_buffers(B, H, L, hd, td, DEV)
+    ops.gemm(x.to(DEV), Wqkv.to(DEV), B * L, 3 * d, d, bias=bqkv.to(DEV), out_t=q_t, ldo_t=d,
+             out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=Lpad, kv_hd=hd)
     slopes = torch.tensor([2.0 ** (-(i + 1)) for i in range(H)])
     scale = 1.0 / math.sqrt(hd) if causal else (1.0 / 32 if hd == 128 else 0.125)
     o = torch.zeros(B * L, d, device=DEV, dtype=td)
-    ops.attention(qkv_t, qkv_t[:, d:], vt, o, B=B, H=H, L=L, hd=hd, ldq=3 * d, ldk=3 * d, ldo=d, Lpad=Lpad,
-                  scale=scale, causal=causal, slopes=slopes.to(DEV) if causal else None, period=30)
+    ops.attention(q_t, kp, vp, o, B=B, H=H, L=L, hd=hd, ldq=d, ldo=d, Lpad=Lpad,
+                  scale=scale, causal=causal, slopes=slopes.to(DEV) if causal else None, period=period)
     torch.cuda.synchronize()
     qkv = (x.float() @ Wqkv.float().t() + bqkv)
     if dtype == BF16:
         qkv = qkv.to(td).float()
-    # GEMM-produced V^T matches the reference V
-    vref = qkv[:, 2 * d:].view(B, L, H, hd).permute(0, 2, 3, 1)
-    assert rel(vt.view(B, H, hd, Lpad)[..., :L].float(), vref) < (2e-5 if dtype == F32 else 1e-2)
     q, k, v = [t.view(B, L, H, hd).transpose(1, 2) for t in qkv.split(d, 1)]
-    ref = mha_ref(q, k, v, scale, alibi(H, L, 30, slopes) if causal else None).transpose(1, 2).reshape(B * L, d)
+    # GEMM-produced packed K / V match the host restatement of the layout
+    kref, vref = pack_ref(k, v, Lpad, dtype)
+    tol = 2e-5 if dtype == F32 else 1e-2
+    assert rel(q_t.float(), qkv[:, :d]) < tol
+    assert rel(kp.float(), kref) < tol and rel(vp.float(), vref) < tol
+    ref = mha_ref(q, k, v, scale, alibi(H, L, period, slopes) if causal else None).transpose(1, 2).reshape(B * L, d)
     assert rel(o.float(), ref) < (3e-5 if dtype == F32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("B,H,L,hd", [(2, 3, 45, 64), (1, 2, 100, 128), (1, 1, 33, 256)])
+def test_pack_kv_is_the_documented_permutation(dtype, B, H, L, hd):
+    g = torch.Generator().manual_seed(B + L)
+    td = ops.tdtype(dtype)
+    d = H * hd
+    kv = torch.randn(B * L, 2 * d, generator=g).to(td)
+    kp, vp, Lpad = ops.kv_buffers(B, H, L, hd, td, DEV)
+    kvd = kv.to(DEV)
+    ops.pack_kv(kvd, kvd[:, d:], kp, vp, B=B, H=H, L=L, Lpad=Lpad, hd=hd, ldk=2 * d, ldv=2 * d)
+    torch.cuda.synchronize()
+    k, v = [t.reshape(B, L, H, hd).transpose(1, 2) for t in kv.split(d, 1)]
+    kref, vref = pack_ref(k, v, Lpad, dtype)
+    assert torch.equal(kp.cpu(), kref) and torch.equal(vp.cpu(), vref)
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])

@@ -8,8 +8,9 @@ dt = torch.bfloat16
 d, H, hd = 1024, 8, 128
 for (B, L, causal) in ((4, 16, True), (4, 32, True), (4, 64, True), (4, 200, True), (4, 200, False), (50, 16, True), (4, 600, True)):
     M = B * L; Lpad = (L + 31) // 32 * 32
-    qkv = torch.randn(M, 3 * d, device=DEV).to(dt); vt = torch.randn(B * H, hd, Lpad, device=DEV).to(dt)
+    qkv = torch.randn(M, d, device=DEV).to(dt)
+    kp = torch.randn(B * H, Lpad * hd, device=DEV).to(dt); vp = torch.randn(B * H, Lpad * hd, device=DEV).to(dt)
     o = torch.empty(M, d, device=DEV, dtype=dt); sl = torch.tensor([2.0 ** -(i + 1) for i in range(H)], device=DEV)
-    us = timeit(lambda: ops.attention(qkv, qkv[:, d:], vt, o, B=B, H=H, L=L, hd=hd, ldq=3 * d, ldk=3 * d, ldo=d, Lpad=Lpad,
+    us = timeit(lambda: ops.attention(qkv, kp, vp, o, B=B, H=H, L=L, hd=hd, ldq=d, ldo=d, Lpad=Lpad,
                                       scale=1 / math.sqrt(hd), causal=causal, slopes=sl if causal else None, period=30))
     print(f"attention B={B} L={L} causal={causal}: {us:6.2f} us  blocks={((L+15)//16)*H*B}")

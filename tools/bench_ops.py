@@ -37,9 +37,10 @@ def main():
     if len(sys.argv) > 2: return
     B, H, L, hd = 4, 8, 200, 128
     Lpad = 224
-    qkv = torch.randn(M, 3 * d, device=DEV).to(dt); vt = torch.randn(B * H, hd, Lpad, device=DEV).to(dt)
+    qkv = torch.randn(M, d, device=DEV).to(dt)
+    kp = torch.randn(B * H, Lpad * hd, device=DEV).to(dt); vp = torch.randn(B * H, Lpad * hd, device=DEV).to(dt)
     o = torch.empty(M, d, device=DEV, dtype=dt); sl = torch.tensor([2.0 ** -(i + 1) for i in range(H)], device=DEV)
-    us = timeit(lambda: ops.attention(qkv, qkv[:, d:], vt, o, B=B, H=H, L=L, hd=hd, ldq=3 * d, ldk=3 * d, ldo=d, Lpad=Lpad,
+    us = timeit(lambda: ops.attention(qkv, kp, vp, o, B=B, H=H, L=L, hd=hd, ldq=d, ldo=d, Lpad=Lpad,
                                       scale=1 / math.sqrt(hd), causal=True, slopes=sl, period=30))
     print(f"attention B={B} H={H} L={L}: {us:7.2f} us")
     x = torch.randn(M, d, device=DEV); g = torch.ones(d, device=DEV); b = torch.zeros(d, device=DEV)
@@ -65,13 +66,14 @@ def fold_costs():
     A = torch.randn(M, d, device=DEV).to(dt); W3 = (torch.randn(3 * d, d, device=DEV) / 32).to(dt); W1 = (torch.randn(d, 2 * d, device=DEV) / 45).to(dt)
     U = torch.randn(M, 2 * d, device=DEV).to(dt)
     b3 = torch.randn(3 * d, device=DEV); b1 = torch.randn(d, device=DEV); res = torch.randn(M, d, device=DEV)
-    qkv = torch.empty(M, 3 * d, device=DEV, dtype=dt); vt = torch.zeros(32, 128, 224, device=DEV, dtype=dt)
+    qkv = torch.empty(M, 3 * d, device=DEV, dtype=dt)
+    kp = torch.zeros(32, 128 * 224, device=DEV, dtype=dt); vp = torch.zeros(32, 128 * 224, device=DEV, dtype=dt)
     stats = torch.rand(16, M, 2, device=DEV) * 1000 + 2000; cs = torch.randn(3 * d, device=DEV)
     o32 = torch.empty(M, d, device=DEV); ot = torch.empty(M, d, device=DEV, dtype=dt)
     gam = torch.ones(d, device=DEV); bet = torch.zeros(d, device=DEV)
-    kw = dict(out_t=qkv, ldo_t=3 * d, out_vt=vt, vt_col0=2 * d, vt_L=200, vt_Lpad=224, vt_hd=128)
-    print(f"qkv plain (vt scatter)        {timeit(lambda: ops.gemm(A, W3, M, 3 * d, d, bias=b3, **kw)):7.2f} us")
-    print(f"qkv no vt scatter             {timeit(lambda: ops.gemm(A, W3, M, 3 * d, d, bias=b3, out_t=qkv, ldo_t=3 * d)):7.2f} us")
+    kw = dict(out_t=qkv, ldo_t=3 * d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=200, kv_Lpad=224, kv_hd=128)
+    print(f"qkv plain (packed K/V)        {timeit(lambda: ops.gemm(A, W3, M, 3 * d, d, bias=b3, **kw)):7.2f} us")
+    print(f"qkv row-major only            {timeit(lambda: ops.gemm(A, W3, M, 3 * d, d, bias=b3, out_t=qkv, ldo_t=3 * d)):7.2f} us")
     print(f"qkv + rowstats + colsum       {timeit(lambda: ops.gemm(A, W3, M, 3 * d, d, bias=b3, ln_stat_in=stats, ln_nparts=16, ln_dim=d, ln_colsum=cs, **kw)):7.2f} us")
     print(f"ffn2 plain                    {timeit(lambda: ops.gemm(U, W1, M, d, 2 * d, bias=b1, resid=res, out_f32=o32)):7.2f} us")
     print(f"ffn2 + out_t                  {timeit(lambda: ops.gemm(U, W1, M, d, 2 * d, bias=b1, resid=res, out_f32=o32, out_t=ot)):7.2f} us")
