@@ -495,4 +495,108 @@ __global__ __launch_bounds__(256) void vq_quant_kernel(const float* z, const flo
   }
 }
 
+// ---- evaluation metrics (computer_metrix.py:84-136, metric/metric.py:115-138): HBM-bound reductions -------------------
+// One workgroup per frame: squared vertex error d2 = ((gx-px)^2 + (gy-py)^2) + (gz-pz)^2 (numpy's order over axis 2, so
+// the per-frame maximum is bit-identical to the reference's), over a vertex region (or all vertices when region == NULL).
+// frame_max[f] = max d2;  frame_sum[2f] = sum d2, frame_sum[2f+1] = sum sqrt(d2)  (double accumulators, fixed order).
+__global__ __launch_bounds__(256) void vertex_err_kernel(const float* gt, const float* pred, const int* region, int R, int V,
+                                                         float* frame_max, double* frame_sum) {
+  __shared__ float rmax[4];
+  __shared__ double rs[4], rn[4];
+  const size_t base = (size_t)blockIdx.x * V * 3;
+  float mx = 0.f;
+  double s2 = 0.0, sn = 0.0;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const size_t o = base + (size_t)(region ? region[r] : r) * 3;
+    const float dx = __fsub_rn(gt[o], pred[o]), dy = __fsub_rn(gt[o + 1], pred[o + 1]), dz = __fsub_rn(gt[o + 2], pred[o + 2]);
+    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    mx = fmaxf(mx, d2);
+    s2 += (double)d2;
+    sn += sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    s2 += __shfl_xor(s2, o, 64);
+    sn += __shfl_xor(sn, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { rmax[threadIdx.x >> 6] = mx; rs[threadIdx.x >> 6] = s2; rn[threadIdx.x >> 6] = sn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    frame_max[blockIdx.x] = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+    frame_sum[2 * blockIdx.x] = (rs[0] + rs[1]) + (rs[2] + rs[3]);
+    frame_sum[2 * blockIdx.x + 1] = (rn[0] + rn[1]) + (rn[2] + rn[3]);
+  }
+}
+// out[0] = mean_f frame_max (LVE / FVE), out[1] = sum d2 / (F R) (EME-style mean), out[2] = sum |d| / (F R) (mean vertex error)
+__global__ __launch_bounds__(256) void vertex_err_final_kernel(const float* frame_max, const double* frame_sum, int F, int R, double* out) {
+  __shared__ double red[3][4];
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int f = threadIdx.x; f < F; f += 256) { a += (double)frame_max[f]; b += frame_sum[2 * f]; c += frame_sum[2 * f + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; red[2][threadIdx.x >> 6] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    out[0] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (double)F;
+    out[1] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / ((double)F * R);
+    out[2] = ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) / ((double)F * R);
+  }
+}
+// Upper-face dynamics (FDD, computer_metrix.py:95-105): s[f, r] = |verts[f, region[r]] - tmpl[region[r]]|^2; population
+// std of s over frames per region vertex, then the mean over the region.  Stage 1: thread = region vertex, block row =
+// frame chunk, partial (sum s, sum s^2) in double; stage 2 folds the chunks in a fixed order.
+__global__ __launch_bounds__(256) void motion_partial_kernel(const float* verts, const float* tmpl, const int* region, int R, int F, int V,
+                                                             double* partial) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const int FC = gridDim.y, fc = blockIdx.y;
+  const int f0 = (int)((long long)F * fc / FC), f1 = (int)((long long)F * (fc + 1) / FC);
+  const int v = region ? region[r] : r;
+  const float tx = tmpl[3 * v], ty = tmpl[3 * v + 1], tz = tmpl[3 * v + 2];
+  double s1 = 0.0, s2 = 0.0;
+  for (int f = f0; f < f1; ++f) {
+    const size_t o = ((size_t)f * V + v) * 3;
+    const float dx = __fsub_rn(verts[o], tx), dy = __fsub_rn(verts[o + 1], ty), dz = __fsub_rn(verts[o + 2], tz);
+    const double s = (double)__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    s1 += s;
+    s2 += s * s;
+  }
+  partial[((size_t)fc * R + r) * 2] = s1;
+  partial[((size_t)fc * R + r) * 2 + 1] = s2;
+}
+__global__ __launch_bounds__(256) void motion_final_kernel(const double* partial, int FC, int R, int F, double* out) {
+  __shared__ double red[4];
+  double acc = 0.0;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int fc = 0; fc < FC; ++fc) { s1 += partial[((size_t)fc * R + r) * 2]; s2 += partial[((size_t)fc * R + r) * 2 + 1]; }
+    const double mu = s1 / F;
+    acc += sqrt(fmax(s2 / F - mu * mu, 0.0));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (double)R;
+}
+
+// F.interpolate(mode='linear', align_corners=True) over time, channels-last x [B, Tin, C] -> y [B, Tout, C]
+// (linear_interpolation, models/hubert.py:62-69 / models/wav2vec.py:61-67: the 50 -> 30 fps resampling of the audio features)
+__global__ void linear_interp_kernel(const float* x, float* y, int B, int Tin, int Tout, int C) {
+  const size_t n = (size_t)B * Tout * C;
+  const float scale = Tout > 1 ? (float)(Tin - 1) / (float)(Tout - 1) : 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int t = (int)((i / C) % Tout);
+    const int b = (int)(i / ((size_t)C * Tout));
+    const float src = __fmul_rn(scale, (float)t);
+    const int i0 = min((int)src, Tin - 1);
+    const int i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+    const float l1 = __fsub_rn(src, (float)i0), l0 = __fsub_rn(1.f, l1);
+    const float* xb = x + (size_t)b * Tin * C + c;
+    y[i] = __fadd_rn(__fmul_rn(l0, xb[(size_t)i0 * C]), __fmul_rn(l1, xb[(size_t)i1 * C]));
+  }
+}
+
 }  // namespace fdm

@@ -255,6 +255,37 @@ int fdm_op_mean_diff(const float* a, const float* b, float* partial, float* out,
   }, stream, "mean_diff");
 }
 
+int fdm_op_vertex_err(const float* gt, const float* pred, const int* region, int R, int F, int V,
+                      float* frame_max, double* frame_sum, double* out, void* stream) {
+  if (!gt || !pred || !frame_max || !frame_sum || !out) return fail(FDM_ERR_ARG, "vertex_err: null operand");
+  if (F <= 0 || V <= 0 || R <= 0 || (!region && R != V)) return fail(FDM_ERR_SHAPE, "vertex_err: bad shape (F %d, V %d, R %d)", F, V, R);
+  return submit([=](hipStream_t s) {
+    hipLaunchKernelGGL(fdm::vertex_err_kernel, dim3(F), dim3(256), 0, s, gt, pred, region, R, V, frame_max, frame_sum);
+    hipLaunchKernelGGL(fdm::vertex_err_final_kernel, dim3(1), dim3(256), 0, s, (const float*)frame_max, (const double*)frame_sum, F, R, out);
+    return hipGetLastError();
+  }, stream, "vertex_err");
+}
+
+int fdm_op_motion_std(const float* verts, const float* tmpl, const int* region, int R, int F, int V,
+                      double* partial, double* out, void* stream) {
+  if (!verts || !tmpl || !partial || !out) return fail(FDM_ERR_ARG, "motion_std: null operand");
+  if (F <= 0 || V <= 0 || R <= 0 || (!region && R != V)) return fail(FDM_ERR_SHAPE, "motion_std: bad shape (F %d, V %d, R %d)", F, V, R);
+  return submit([=](hipStream_t s) {
+    const int FC = F < 64 ? F : 64;
+    hipLaunchKernelGGL(fdm::motion_partial_kernel, dim3((R + 255) / 256, FC), dim3(256), 0, s, verts, tmpl, region, R, F, V, partial);
+    hipLaunchKernelGGL(fdm::motion_final_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, FC, R, F, out);
+    return hipGetLastError();
+  }, stream, "motion_std");
+}
+
+int fdm_op_linear_interp(const float* x, float* y, int B, int Tin, int Tout, int C, void* stream) {
+  if (!x || !y || B <= 0 || Tin <= 0 || Tout <= 0 || C <= 0) return fail(FDM_ERR_ARG, "linear_interp: bad argument");
+  return submit([=](hipStream_t s) {
+    hipLaunchKernelGGL(fdm::linear_interp_kernel, dim3(grid_for((long long)B * Tout * C)), dim3(256), 0, s, x, y, B, Tin, Tout, C);
+    return hipGetLastError();
+  }, stream, "linear_interp");
+}
+
 int fdm_op_adain(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps, void* stream) {
   if (!content || !style || !out || NC <= 0 || Lc < 2 || Ls < 2) return fail(FDM_ERR_ARG, "adain: bad argument");
   return submit([=](hipStream_t s) {

@@ -58,6 +58,9 @@ SYMBOLS = {
     "fdm_op_layernorm": (ci, [C.POINTER(LnArgs), vp]),
     "fdm_op_sched_step": (ci, [C.POINTER(SchedArgs), vp]),
     "fdm_op_cast": (ci, [vp, vp, ll, ci, vp]),
+    "fdm_op_vertex_err": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]),
+    "fdm_op_motion_std": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
+    "fdm_op_linear_interp": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "fdm_op_bias_act": (ci, [vp, vp, vp, ll, ci, ci, vp]),
     "fdm_op_add_rows": (ci, [vp, ci, ci, vp, ci, ci, vp, ci, ci, vp, ll, ci, vp]),
     "fdm_op_small_linear": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, vp]),

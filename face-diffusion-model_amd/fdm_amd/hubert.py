@@ -123,8 +123,10 @@ class HubertPlan:
             self.final_ln = (g("encoder.layer_norm.weight"), g("encoder.layer_norm.bias"))
         self.stream.synchronize()
 
-    def forward(self, wav):
-        """wav [B, n] fp32 (processor-normalised) -> last_hidden_state [B, N, D] fp32."""
+    def forward(self, wav, frame_num=None, interp_fps=None):
+        """wav [B, n] fp32 (processor-normalised) -> last_hidden_state [B, N, D] fp32.
+        frame_num: keep at most 2*frame_num conv frames (models/hubert.py:97-98).  interp_fps=(in, out): resample the
+        conv features (linear, align_corners) to frame_num / int(T/in*out) frames instead of the even crop."""
         dv, td, dt, cfg = self.device, self.td, self.dtype, self.cfg
         D, N_HEAD, FFN = cfg.D, cfg.H, cfg.FFN
         if wav.dim() == 1:
@@ -135,6 +137,8 @@ class HubertPlan:
         if Ts[-1] < 2:
             raise FdmError(f"audio too short: {n} samples")
         N = Ts[-1] - (Ts[-1] % 2)
+        if frame_num and not interp_fps and N > frame_num * 2:
+            N = frame_num * 2
         cur = torch.cuda.current_stream(dv)
         self.stream.wait_stream(cur)
         z = lambda *s, dtp=torch.float32: torch.empty(*s, device=dv, dtype=dtp)
@@ -174,6 +178,13 @@ class HubertPlan:
                 Tin = To
             # --- even crop (models/hubert.py:95-96) + feature projection ---
             T6 = Ts[6]
+            if interp_fps:
+                N = int(frame_num) if frame_num else int(T6 / float(interp_fps[0]) * interp_fps[1])
+                if N < 2:
+                    raise FdmError(f"interpolated length {N} too short")
+                gi = z(B * N, CD)
+                ops.linear_interp(g6, gi, B, T6, N, CD)
+                g6, T6 = gi, N
             ft = z(B * T6, CD, dtp=td)
             ops.layernorm(g6, self.fp_ln[0], self.fp_ln[1], B * T6, CD, y_t=ft, dtype=dt)
             M = B * N

@@ -23,7 +23,7 @@ from types import SimpleNamespace
 import torch
 import torch.nn as nn
 
-from . import presets, schedule, synth
+from . import ops, presets, schedule, synth
 from ._lib import BF16, F32, FdmError
 from .denoiser import DenoiserPlan
 from .hubert import HUBERT_LARGE, WAV2VEC2_BASE, HubertPlan, num_frames
@@ -60,6 +60,20 @@ def _tensor_key(t):
 
 
 # --------------------------------------------------------------------------------------------------
+def linear_interpolation(features, input_fps, output_fps, output_len=None):
+    """models/hubert.py:62-69: resample [B, T, C] features along time with F.interpolate(mode='linear',
+    align_corners=True); output_len defaults to int(T / input_fps * output_fps).  HIP kernel (fdm_op_linear_interp)."""
+    if not features.is_cuda:
+        raise FdmError("linear_interpolation runs on the HIP path only: move the features to the GPU")
+    B, T, Cn = features.shape
+    if output_len is None:
+        output_len = int(T / float(input_fps) * output_fps)
+    x = features.detach().to(torch.float32).contiguous()
+    y = torch.empty(B, output_len, Cn, device=x.device)
+    ops.linear_interp(x, y, B, T, output_len, Cn)
+    return y
+
+
 class HubertModel(ParamTree):
     """HuBERT-large (24 layers) with the reference's forward override; `from_pretrained` loads a local
     HF checkpoint directory when present, else keeps the seeded random init (no network here)."""
@@ -101,13 +115,15 @@ class HubertModel(ParamTree):
         return self._plan
 
     def forward(self, input_values, attention_mask=None, output_attentions=None, output_hidden_states=None,
-                return_dict=None, frame_num=None):
+                return_dict=None, frame_num=None, interp_fps=None):
+        """models/hubert.py:75-146.  frame_num crops the conv features to 2*frame_num frames BEFORE the encoder
+        (:97-98).  Build-added `interp_fps=(input_fps, output_fps)`: resample the conv features with
+        linear_interpolation (to `frame_num` frames when given) instead of the even crop -- the CodeTalker-style
+        'vocaset' branch the shipped file dropped; default None = shipped behaviour."""
         if not input_values.is_cuda:
             raise FdmError("HubertModel.forward runs on the HIP path only: move the audio to the GPU")
         # a `str` second positional argument (models/fdm_vocaset.py:59 passes 'vocaset') is ignored (SURVEY.md a17b)
-        out = self._get_plan(input_values.device).forward(input_values)
-        if frame_num and out.shape[1] > frame_num * 2:
-            out = out[:, : frame_num * 2]
+        out = self._get_plan(input_values.device).forward(input_values, frame_num=frame_num, interp_fps=interp_fps)
         return SimpleNamespace(last_hidden_state=out, hidden_states=None, attentions=None)
 
 

@@ -160,6 +160,18 @@ def mean_diff(a, b, l1=False):
     return out
 
 
+def linear_interp(x, y, B, Tin, Tout, C):
+    check(lib().fdm_op_linear_interp(_p(x), _p(y), B, Tin, Tout, C, stream()))
+
+
+def vertex_err(gt, pred, region, R, F, V, frame_max, frame_sum, out):
+    check(lib().fdm_op_vertex_err(_p(gt), _p(pred), _p(region), R, F, V, _p(frame_max), _p(frame_sum), _p(out), stream()))
+
+
+def motion_std(verts, tmpl, region, R, F, V, partial, out):
+    check(lib().fdm_op_motion_std(_p(verts), _p(tmpl), _p(region), R, F, V, _p(partial), _p(out), stream()))
+
+
 def adain(content, style, out, NC, Lc, Ls, eps=1e-5):
     check(lib().fdm_op_adain(_p(content), _p(style), _p(out), NC, Lc, Ls, eps, stream()))
 

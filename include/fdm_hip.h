@@ -192,6 +192,20 @@ int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta,
 /* out[0] = mean(|a - b|^p), p = 2 (l1 = 0) or 1: the forward value of p_losses' F.mse_loss / F.l1_loss
  * (diffusion_BIWI_encoder_decoder.py:744-749); partial: >= 1024 floats of scratch; deterministic order */
 int fdm_op_mean_diff(const float* a, const float* b, float* partial, float* out, long long n, int l1, void* stream);
+/* Evaluation metrics over vertex sequences gt, pred [F, V, 3] fp32 (computer_metrix.py:84-136, metric/metric.py:115-138).
+ * region: R int32 vertex indices (NULL with R == V: all vertices).  Per frame: frame_max[f] = max_r d2 (bit-identical to
+ * numpy's float32 value), frame_sum[2f] = sum_r d2, frame_sum[2f+1] = sum_r sqrt(d2) with d2 = |gt - pred|^2;
+ * out[0] = mean_f frame_max ("Lip/Face Vertex Error"), out[1] = mean d2 ("Emotion Mean Error"), out[2] = mean |d|
+ * ("Mean Vertex Error"; compute_diversity's pairwise distance).  Deterministic (fixed reduction order).                  */
+int fdm_op_vertex_err(const float* gt, const float* pred, const int* region, int R, int F, int V,
+                      float* frame_max, double* frame_sum, double* out, void* stream);
+/* out[0] = mean_r std_f(|verts[f, region[r]] - tmpl[region[r]]|^2): the per-sequence motion statistic whose gt - pred
+ * difference is FDD (computer_metrix.py:95-107).  partial: >= 2 * min(F, 64) * R doubles of scratch.                     */
+int fdm_op_motion_std(const float* verts, const float* tmpl, const int* region, int R, int F, int V,
+                      double* partial, double* out, void* stream);
+/* F.interpolate(mode='linear', align_corners=True) over time, x [B, Tin, C] -> y [B, Tout, C] fp32
+ * (linear_interpolation, models/hubert.py:62-69: optional 50 -> 30 fps resampling of the conv features)                  */
+int fdm_op_linear_interp(const float* x, float* y, int B, int Tin, int Tout, int C, void* stream);
 /* AdaIN (utiles/adaIN.py:4-22): content, style [N, C, Lc], [N, C, Ls] -> out [N, C, Lc] */
 int fdm_op_adain(const float* content, const float* style, float* out, int NC, int Lc, int Ls, float eps, void* stream);
 /* regroup [B, T, d] -> [groups, B, T + 2*pad, d/groups] zero padded (HuBERT positional conv input) */

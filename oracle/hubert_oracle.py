@@ -68,11 +68,32 @@ def encoder_layer(w, p, h):
                         w[p + "feed_forward.output_dense.bias"])
 
 
-def hubert_forward_clip(w, wav, n_layers=24, pre="", trace=None):
-    """wav [n] fp32 (already processor-normalised) -> last_hidden_state [N, 1024]."""
+def linear_interpolation(features, input_fps, output_fps, output_len=None):
+    """models/hubert.py:62-69 restated without F.interpolate: align_corners linear resampling of [B, T, C] along T.
+    src = t * (T-1)/(T_out-1); i0 = floor(src); y = (1-l)*x[i0] + l*x[min(i0+1, T-1)], all in fp32."""
+    B, T, C = features.shape
+    if output_len is None:
+        output_len = int(T / float(input_fps) * output_fps)
+    scale = torch.tensor((T - 1) / (output_len - 1) if output_len > 1 else 0.0, dtype=torch.float32)
+    src = scale * torch.arange(output_len, dtype=torch.float32)
+    i0 = src.floor().long().clamp(max=T - 1)
+    i1 = (i0 + 1).clamp(max=T - 1)
+    l1 = (src - i0.float()).view(1, -1, 1)
+    return (1.0 - l1) * features[:, i0] + l1 * features[:, i1]
+
+
+def hubert_forward_clip(w, wav, n_layers=24, pre="", trace=None, frame_num=None, interp_fps=None):
+    """wav [n] fp32 (already processor-normalised) -> last_hidden_state [N, 1024].
+    frame_num: models/hubert.py:97-98 (crop of the conv features).  interp_fps=(in, out): build-defined optional
+    branch: resample the conv features with linear_interpolation instead of the even crop."""
     f = feature_extractor(w, wav, pre)
-    if f.shape[0] % 2 != 0:                       # models/hubert.py:95-96
-        f = f[:-1]
+    if interp_fps:
+        f = linear_interpolation(f.unsqueeze(0), interp_fps[0], interp_fps[1], output_len=frame_num)[0]
+    else:
+        if f.shape[0] % 2 != 0:                       # models/hubert.py:95-96
+            f = f[:-1]
+        if frame_num and f.shape[0] > frame_num * 2:  # models/hubert.py:97-98
+            f = f[: frame_num * 2]
     if trace is not None:
         trace["conv"] = f.clone()
     x = F.layer_norm(f, (f.shape[1],), w[pre + "feature_projection.layer_norm.weight"],
@@ -90,9 +111,10 @@ def hubert_forward_clip(w, wav, n_layers=24, pre="", trace=None):
                         w[pre + "encoder.layer_norm.bias"], EPS)
 
 
-def hubert_forward(w, wav, n_layers=24, pre=""):
+def hubert_forward(w, wav, n_layers=24, pre="", frame_num=None, interp_fps=None):
     """wav [B, n] -> [B, N, 1024]; clips are independent."""
-    return torch.stack([hubert_forward_clip(w, wav[b], n_layers, pre) for b in range(wav.shape[0])])
+    return torch.stack([hubert_forward_clip(w, wav[b], n_layers, pre, frame_num=frame_num, interp_fps=interp_fps)
+                        for b in range(wav.shape[0])])
 
 
 def processor_normalize(wav, pad_seconds=0.0, sr=16000):

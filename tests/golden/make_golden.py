@@ -471,6 +471,108 @@ def g12_vq_encode():
     save("vq_encode", **out)
 
 
+def g13_metrics():
+    """Evaluation metrics: run the reference's own computer_metrix.main() and
+    compute_diversity() on a seeded synthetic dataset written to a temp dir; keep the numbers it prints."""
+    import contextlib
+    import io
+    import json
+    import pickle
+    import re
+    import tempfile
+    import computer_metrix as CM
+    from oracle import metrics_oracle as MO
+    res = {}
+    for dataset, nv, sentences, subjects in (("vocaset", 6172, [str(i) for i in range(46, 51)], ["FaceTalk_A", "FaceTalk_B"]),
+                                             ("BIWI", 23370, ["e" + str(i).zfill(2) for i in range(37, 41)], ["F2", "M3"])):
+        seed, frames = (7 if dataset == "vocaset" else 9), 11
+        rs = np.random.RandomState(seed + 100)
+        mouth = sorted(rs.choice(nv, 300, replace=False).tolist())
+        upper = sorted(rs.choice(nv, 200, replace=False).tolist())
+        with tempfile.TemporaryDirectory() as td:
+            os.makedirs(os.path.join(td, "gt")); os.makedirs(os.path.join(td, "pred")); os.makedirs(os.path.join(td, "regions"))
+            templates, seqs = {}, {}
+            for si, subj in enumerate(subjects):
+                tmpl, ss = MO.synth_sequences(seed + si, len(sentences), frames, nv)
+                templates[subj] = tmpl.reshape(-1)
+                for sent, (gt, pred) in zip(sentences, ss):
+                    np.save(os.path.join(td, "gt", f"{subj}_{sent}.npy"), gt.reshape(gt.shape[0], -1))
+                    np.save(os.path.join(td, "pred", f"{subj}_{sent}.npy"), pred.reshape(pred.shape[0], -1))
+                    # a second prediction "conditioned on" the other subject, for compute_diversity
+                    np.save(os.path.join(td, "pred", f"{subj}_{sent}_condition_{subjects[0]}.npy"), pred.reshape(pred.shape[0], -1))
+                    np.save(os.path.join(td, "pred", f"{subj}_{sent}_condition_{subjects[1]}.npy"), gt.reshape(gt.shape[0], -1))
+                    seqs[(subj, sent)] = (gt, pred)
+            with open(os.path.join(td, "templates.pkl"), "wb") as f:
+                pickle.dump(templates, f)
+            if dataset == "BIWI":
+                open(os.path.join(td, "regions", "lve.txt"), "w").write(", ".join(map(str, mouth)))
+                open(os.path.join(td, "regions", "fdd.txt"), "w").write(", ".join(map(str, upper)))
+            else:
+                mm = np.zeros(nv); mm[mouth] = 0.5
+                um = np.zeros(nv); um[upper] = 0.9
+                open(os.path.join(td, "regions", "weighted_mouth_mask.txt"), "w").write("\n".join(f"{v:.3f}" for v in mm) + "\n")
+                open(os.path.join(td, "regions", "forehead_mask.txt"), "w").write("\n".join(f"{v:.3f}" for v in um) + "\n")
+            argv = ["x", "--train_subjects", " ".join(subjects), "--pred_path", os.path.join(td, "pred"),
+                    "--gt_path", os.path.join(td, "gt"), "--region_path", os.path.join(td, "regions"),
+                    "--templates_path", os.path.join(td, "templates.pkl"), "--dataset", dataset]
+            buf = io.StringIO()
+            old = sys.argv
+            try:
+                with contextlib.redirect_stdout(buf):
+                    sys.argv = argv
+                    CM.main()
+                    sys.argv = argv + ["--test_subjects", " ".join(subjects)]
+                    CM.compute_diversity()
+            finally:
+                sys.argv = old
+        txt = buf.getvalue()
+        grab = lambda label: float(re.findall(r"^" + re.escape(label) + r": ([-+0-9.e]+)$", txt, re.M)[-1])
+        r = dict(seed=seed, frames=frames, nv=nv, subjects=subjects, sentences=sentences, mouth=mouth, upper=upper,
+                 frame_number=int(re.findall(r"Frame Number: (\d+)", txt)[0]),
+                 mean_vertex_error=grab("Mean Vertex Error"), lip_vertex_error=grab("Lip Vertex Error"),
+                 fdd=grab("FDD"), abs_fdd=grab("ABS FDD"), diversity=grab("Diversity"))
+        # oracle restatement on the same data
+        gts = np.concatenate([seqs[(a, b)][0] for a in subjects for b in sentences])
+        prs = np.concatenate([seqs[(a, b)][1] for a in subjects for b in sentences])
+        fd = [MO.fdd(seqs[(a, b)][0], seqs[(a, b)][1], templates[a], upper) for a in subjects for b in sentences]
+        mine = dict(mean_vertex_error=MO.mean_vertex_error(gts, prs), lip_vertex_error=MO.max_vertex_error(gts, prs, mouth),
+                    fdd=sum(fd) / len(fd), abs_fdd=sum(abs(v) for v in fd) / len(fd))
+        for k, v in mine.items():
+            print(f"  {dataset} {k}: reference prints {r[k]:.4e}, oracle {v:.6e}")
+            assert abs(v - r[k]) <= 6e-5 * abs(r[k]) + 1e-12, (k, v, r[k])
+        res[dataset] = r
+    json.dump(res, open(os.path.join(HERE, "metrics.json"), "w"))
+    print("  wrote metrics.json")
+
+
+def g14_hubert_frames():
+    """frame_num crop before the encoder (models/hubert.py:97-98) on the reference HuBERT (2 layers), and the
+    reference's linear_interpolation (models/hubert.py:62-69) on random features."""
+    import models.hubert as rh
+    out = {}
+    refshim.install(hubert_layers=2)
+    hm = rh.HubertModel.from_pretrained("x").eval()
+    wh = W.make_hubert_weights(2)
+    hm.load_state_dict(wh, strict=True)
+    g = torch.Generator().manual_seed(12)
+    wav = HO.processor_normalize(torch.randn(32000, generator=g) * 0.1)
+    ref = hm(wav.unsqueeze(0), frame_num=20).last_hidden_state[0]
+    ours = HO.hubert_forward_clip(wh, wav, 2, frame_num=20)
+    print(f"  frame_num=20: out {tuple(ref.shape)} |ref-oracle|={mad(ref, ours):.3e}")
+    out["out_L2_2s_fn20"] = ref.numpy()
+    refshim.install(hubert_layers=24)
+    for (T, To, C) in ((99, 60, 512), (498, 299, 64), (7, 20, 16), (5, 1, 8)):
+        x = torch.randn(2, T, C, generator=g)
+        y = rh.linear_interpolation(x, 50, 30, output_len=To)
+        mine = HO.linear_interpolation(x, 50, 30, output_len=To)
+        print(f"  linear_interpolation {T}->{To}: |ref-oracle|={mad(y, mine):.3e}")
+        out[f"interp_{T}_{To}_{C}_x"] = x.numpy()
+        out[f"interp_{T}_{To}_{C}_y"] = y.numpy()
+    y = rh.linear_interpolation(x, 50, 30)
+    assert y.shape[1] == HO.linear_interpolation(x, 50, 30).shape[1]
+    save("hubert_frames", **out)
+
+
 ALL = {
     "schedule": g1_schedule, "masks": g2_masks,
     "fdm_step_vocaset": lambda: g3_fdm_step("vocaset"),
@@ -481,6 +583,7 @@ ALL = {
     "chains_mead": lambda: g4_chains("mead"),
     "chains_vocaset_tiny": lambda: g4_chains("vocaset_tiny"),
     "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio, "state_keys": g10_state_keys, "wav2vec": g11_wav2vec, "vq_encode": g12_vq_encode,
+    "metrics": g13_metrics, "hubert_frames": g14_hubert_frames,
 }
 
 if __name__ == "__main__":

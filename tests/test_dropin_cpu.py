@@ -75,3 +75,18 @@ def test_schedule_helpers_and_cli_flags(dropin):
     assert schedule.ddim_time_pairs(100)[0] == (999, 989) and schedule.ddim_time_pairs(100)[-1] == (9, -1)
     x = pipeline.processor_normalize(np.arange(100, dtype=np.float32), pad_seconds=1.0)
     assert x.shape == (16100,) and abs(float(x[:100].mean())) < 1e-6 and float(x[100:].max()) == 0.0
+
+
+def test_metric_and_resampling_dropins_import_with_the_reference_names(dropin):
+    """computer_metrix.py (main, compute_diversity), metric/metric.py arithmetic, models/hubert.py linear_interpolation."""
+    import computer_metrix as cm
+    from metric import metric as mm
+    from models.hubert import HubertModel, linear_interpolation
+    from models.wav2vec import linear_interpolation as li2
+    assert callable(cm.main) and callable(cm.compute_diversity) and callable(mm.mead_vertex_metrics)
+    assert list(inspect.signature(linear_interpolation).parameters) == ["features", "input_fps", "output_fps", "output_len"]
+    assert li2 is linear_interpolation
+    assert "frame_num" in inspect.signature(HubertModel.forward).parameters
+    from fdm_amd._lib import FdmError
+    with pytest.raises(FdmError):      # no CPU fallback
+        linear_interpolation(torch.zeros(1, 4, 4), 50, 30)

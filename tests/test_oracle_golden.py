@@ -177,3 +177,36 @@ def test_vq_encode_round_trip(golden, preset):
     zq, idx = VO.quant(w, preset, h, emo)
     assert np.array_equal(idx.numpy().astype(np.int16), g[f"{preset}_idx"])
     assert mad(VO.decode(w, preset, zq)[0][:, ::16], g[f"{preset}_dec_cols16"]) < TOL
+
+
+def test_hubert_frame_num_and_linear_interpolation(golden):
+    """models/hubert.py:97-98 (frame_num crop before the encoder) and :62-69 (linear_interpolation)."""
+    g = golden("hubert_frames")
+    gen = torch.Generator().manual_seed(12)
+    wav = HO.processor_normalize(torch.randn(32000, generator=gen) * 0.1)
+    out = HO.hubert_forward_clip(W.make_hubert_weights(2), wav, 2, frame_num=20)
+    assert out.shape == (40, 1024) and mad(out, g["out_L2_2s_fn20"]) < TOL
+    for key in [k for k in g.files if k.startswith("interp_") and k.endswith("_x")]:
+        _, T, To, C, _ = key.split("_")
+        y = HO.linear_interpolation(torch.from_numpy(g[key]), 50, 30, output_len=int(To))
+        assert mad(y, g[key[:-1] + "y"]) < 1e-6
+    assert HO.linear_interpolation(torch.zeros(1, 100, 4), 50, 30).shape[1] == 60
+
+
+@pytest.mark.parametrize("dataset", ["vocaset", "BIWI"])
+def test_metrics_oracle_reproduces_the_numbers_the_reference_printed(dataset):
+    """computer_metrix.py main(): the reference itself was run on this seeded dataset (make_golden.py g13)."""
+    from oracle import metrics_oracle as MO
+    from tests.metrics_data import golden_metrics, sequences
+    rec = golden_metrics()[dataset]
+    templates, seqs = sequences(rec)
+    order = [(a, b) for a in rec["subjects"] for b in rec["sentences"]]
+    gts = np.concatenate([seqs[k][0] for k in order])
+    prs = np.concatenate([seqs[k][1] for k in order])
+    assert gts.shape[0] == rec["frame_number"]
+    fd = [MO.fdd(seqs[k][0], seqs[k][1], templates[k[0]], rec["upper"]) for k in order]
+    got = dict(mean_vertex_error=MO.mean_vertex_error(gts, prs), lip_vertex_error=MO.max_vertex_error(gts, prs, rec["mouth"]),
+               fdd=sum(fd) / len(fd), abs_fdd=sum(abs(v) for v in fd) / len(fd),
+               diversity=float(np.mean([MO.mean_vertex_error(seqs[k][0], seqs[k][1]) for k in order])))
+    for k, v in got.items():      # the reference prints 5 significant digits
+        assert abs(v - rec[k]) <= 6e-5 * abs(rec[k]), (k, v, rec[k])
