@@ -55,8 +55,52 @@ __device__ __forceinline__ void gemm_load_rowstats(const fdm_gemm_args& p, int m
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes are ordered by the k loop's first raw s_barrier
 }
 
-template <typename T, int BM, int BN, int WM = 2, int WN = 2>
-__device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16], int m0, int n0, int z,
+// Everything the epilogue reads from memory (bias, folded-LayerNorm vectors, the residual tile) is fetched by
+// gemm_epi_preload BEFORE the k loop, so the epilogue is compute + stores only.  Left inside the epilogue these loads
+// sit behind the stores of earlier fragments (the output pointers may alias the inputs as far as the compiler knows),
+// one exposed load latency per (mi, ni) fragment: measured 11 us of fixed cost on a 96x128 tile, ~1 us on 64x64.
+// Issued first, they are older than every ring load, so the k loop's counted vmcnt waits cover them too.
+template <int MI, int NI> struct EpiPre { f32x4 csv[NI], bv[NI], gmv[NI], btv[NI], rv[MI][NI]; };
+
+template <typename T, int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void gemm_epi_preload(const fdm_gemm_args& p, int m0, int n0, int z, int wm, int wn, int g, int r16,
+                                                 bool ln_capable, EpiPre<BM / WM / 16, BN / WN / 16>& e) {
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  const int M = p.M, N = p.N;
+  const bool use_ln = ln_capable && p.ln_stat_in;
+  const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
+  const size_t ocol = (size_t)z * p.out_batch_stride;
+  const bool vec_r = p.resid && (p.ldr % 4 == 0) && (((uintptr_t)(p.resid + ocol)) % 16 == 0);
+  const bool pre_cs = use_ln && p.ln_colsum, pre_rln = use_ln && p.rln_gamma && p.resid;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int n = n0 + wn * (BN / WN) + ni * 16 + 4 * g;
+    const bool full = (n + 3 < N);
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+    e.csv[ni] = (pre_cs && full) ? *(const f32x4*)(p.ln_colsum + n) : zero;
+    e.bv[ni] = (bias && full) ? *(const f32x4*)(bias + n) : zero;
+    e.gmv[ni] = (pre_rln && full) ? *(const f32x4*)(p.rln_gamma + n) : zero;
+    e.btv[ni] = (pre_rln && full) ? *(const f32x4*)(p.rln_beta + n) : zero;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int m = m0 + wm * (BM / WM) + mi * 16 + r16;
+      const size_t rrow = p.resid_row_mod > 0 ? (size_t)(min(m, M - 1) % p.resid_row_mod) : (size_t)min(m, M - 1);
+      e.rv[mi][ni] = (p.resid && vec_r && full && m < M) ? *(const f32x4*)(p.resid + ocol + rrow * p.ldr + n) : zero;
+    }
+  }
+}
+
+// HEAVY = the activation may be one of the transcendental ones (Mish, GELU): their libm expansions are hundreds of
+// instructions per element, so kernels for the plain / ReLU / LeakyReLU GEMMs (33 of the step's 34) are built without.
+template <bool HEAVY> __device__ __forceinline__ float gemm_act(float v, int act) {
+  if constexpr (HEAVY) return act_apply(v, act);
+  else return act == ACT_RELU ? fmaxf(v, 0.f) : (act == ACT_LEAKY02 ? (v > 0.f ? v : 0.2f * v) : v);
+}
+__host__ __device__ inline bool gemm_act_is_heavy(int act) { return act == ACT_MISH || act == ACT_GELU_ERF || act == ACT_GELU_TANH; }
+
+template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true>
+__device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
+                                              const EpiPre<BM / WM / 16, BN / WN / 16>& e, int m0, int n0, int z,
                                               int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   const int M = p.M, N = p.N;
@@ -79,6 +123,89 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   const int kv_H = p.out_vp ? (N - p.vp_col0) / p.kv_hd : 0;
   const size_t kv_blk = (size_t)p.kv_Lpad * p.kv_hd;        // elements per (clip, head) block of the packed buffers
   const int kcol_lo = p.out_kp ? p.kp_col0 : N, kcol_hi = p.out_kp ? (p.out_vp ? p.vp_col0 : N) : N;
+  const bool pre_cs = use_ln && p.ln_colsum, pre_rln = use_ln && p.rln_gamma && p.resid;
+  const f32x4 (&csv)[NI] = e.csv; const f32x4 (&bv)[NI] = e.bv; const f32x4 (&gmv)[NI] = e.gmv; const f32x4 (&btv)[NI] = e.btv;
+  const f32x4 (&rv)[MI][NI] = e.rv;
+  // Interior tiles (no column edge, vectorisable pointers, the whole tile in one of the Q / K / V column ranges) take a
+  // lean straight-line path.  The general path below handles every edge case but is ~1000 instructions of branches per
+  // fragment: measured, the epilogue's code size IS the kernel's fixed cost (~0.3 us per 1000 lines of ISA on top of the
+  // launch floor: 4.5 us for this 64x64 kernel, 16 us for a 128x128 tile on 4 waves), so the common case must be short.
+  const int kv_mode = (!p.out_kp && !p.out_vp) ? 0
+                    : (n0 + BN <= (p.out_kp ? kcol_lo : p.vp_col0)) ? 0
+                    : (p.out_kp && n0 >= kcol_lo && n0 + BN <= kcol_hi) ? 1
+                    : vt_tile ? 2 : -1;
+  const bool lean = kv_mode >= 0 && n0 + BN <= N && (vec_f32 || !p.out_f32) && (vec_t || !p.out_t) && (vec_r || !p.resid) &&
+                    (p.kv_hd % 16 == 0 || kv_mode != 1);
+  if (lean) {
+    const int ncol = n0 + wn * (BN / WN) + 4 * g;            // this lane's column in fragment ni = 0
+    const int KH = (kv_mode == 1) ? (kcol_hi - kcol_lo) / p.kv_hd : 1;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      const int lrow = wm * (BM / WM) + mi * 16 + r16;
+      const int m = m0 + lrow;
+      if (m >= M) continue;
+      const float mu = use_ln ? rowstat[2 * lrow] : 0.f, rs = use_ln ? rowstat[2 * lrow + 1] : 1.f;
+      float ps = 0.f, pq = 0.f;
+      float* o32 = p.out_f32 ? p.out_f32 + ocol + (size_t)m * p.ldo_f32 + ncol : nullptr;
+      T* ot = p.out_t ? (T*)p.out_t + ocol + (size_t)m * p.ldo_t + ncol : nullptr;
+      T* okp = nullptr;
+      int kv_l = 0;
+      if (kv_mode == 1) {
+        const int kv_b = m / p.kv_L;
+        kv_l = m - kv_b * p.kv_L;
+        okp = (T*)p.out_kp + (size_t)kv_b * KH * kv_blk;
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        f32x4 v = acc[mi][ni];
+        if (pre_cs) v = (v - mu * csv[ni]) * rs;
+        if (bias) v += bv[ni];
+        if (p.act != ACT_NONE) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = gemm_act<HEAVY>(v[j], p.act);
+        }
+        if (p.resid) v += pre_rln ? (rv[mi][ni] - mu) * rs * gmv[ni] + btv[ni] : rv[mi][ni];
+        if (do_stat) {
+          ps += (v[0] + v[1]) + (v[2] + v[3]);
+          pq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        }
+        if (kv_mode == 2) {
+          const int nl = wn * (BN / WN) + ni * 16 + 4 * g;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<T>(v[j]);
+          continue;
+        }
+        if (kv_mode == 1) {
+          const int cc = ncol + ni * 16 - kcol_lo;
+          const int h = cc / p.kv_hd, e2 = cc - h * p.kv_hd;
+          T* dst = okp + (size_t)h * kv_blk + kp_offset<T>(kv_l, e2, p.kv_hd);
+          if constexpr (sizeof(T) == 4) {
+            *(f32x4*)dst = v;
+          } else {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)dst = o;
+          }
+          continue;
+        }
+        if (o32) *(f32x4*)(o32 + ni * 16) = v;
+        if (ot) {
+          if constexpr (sizeof(T) == 4) {
+            *(f32x4*)(ot + ni * 16) = v;
+          } else {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+            *(bf16x4*)(ot + ni * 16) = o;
+          }
+        }
+      }
+      if (do_stat) {
+        ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+        pq += __shfl_xor(pq, 16, 64); pq += __shfl_xor(pq, 32, 64);
+        if (g == 0) { comb[(wn * BM + lrow) * 2] = ps; comb[(wn * BM + lrow) * 2 + 1] = pq; }
+      }
+    }
+  } else {
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int lrow = wm * (BM / WM) + mi * 16 + r16;
@@ -95,10 +222,9 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       if (n >= N) continue;
       f32x4 v = acc[mi][ni];
       const bool full = (n + 3 < N);
-      if (use_ln && p.ln_colsum) {      // LN(x) W^T == rstd (x W'^T - mu colsum(W'))
+      if (pre_cs) {      // LN(x) W^T == rstd (x W'^T - mu colsum(W'))
         if (full) {
-          const f32x4 cs = *(const f32x4*)(p.ln_colsum + n);
-          v = (v - mu * cs) * rs;
+          v = (v - mu * csv[ni]) * rs;
         } else {
           for (int j = 0; j < 4; ++j)
             if (n + j < N) v[j] = (v[j] - mu * p.ln_colsum[n + j]) * rs;
@@ -106,8 +232,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       }
       if (bias) {
         if (full) {
-          f32x4 b = *(const f32x4*)(bias + n);
-          v += b;
+          v += bv[ni];
         } else {
           for (int j = 0; j < 4; ++j)
             if (n + j < N) v[j] += bias[n + j];
@@ -115,20 +240,19 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       }
       if (p.act != ACT_NONE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = act_apply(v[j], p.act);
+        for (int j = 0; j < 4; ++j) v[j] = gemm_act<HEAVY>(v[j], p.act);
       }
       if (p.resid) {
         const float* rp = p.resid + ocol + rrow * p.ldr + n;
-        if (use_ln && p.rln_gamma) {    // residual = LayerNorm(raw row) computed on the fly
+        if (pre_rln) {    // residual = LayerNorm(raw row) computed on the fly
           if (full && vec_r) {
-            const f32x4 xr = *(const f32x4*)rp, gm = *(const f32x4*)(p.rln_gamma + n), bt = *(const f32x4*)(p.rln_beta + n);
-            v += (xr - mu) * rs * gm + bt;
+            v += (rv[mi][ni] - mu) * rs * gmv[ni] + btv[ni];
           } else {
             for (int j = 0; j < 4; ++j)
               if (n + j < N) v[j] += (rp[j] - mu) * rs * p.rln_gamma[n + j] + p.rln_beta[n + j];
           }
         } else if (full && vec_r) {
-          v += *(const f32x4*)rp;
+          v += rv[mi][ni];
         } else {
           for (int j = 0; j < 4; ++j)
             if (n + j < N) v[j] += rp[j];
@@ -198,6 +322,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       pq += __shfl_xor(pq, 16, 64); pq += __shfl_xor(pq, 32, 64);
       if (g == 0) { comb[(wn * BM + lrow) * 2] = ps; comb[(wn * BM + lrow) * 2 + 1] = pq; }
     }
+  }
   }
   if (vt_tile) {
     __syncthreads();
@@ -319,7 +444,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const fdm_gemm_args p) {
     }
     __syncthreads();
   }
-  gemm_epilogue<T, BM, BN>(p, acc, m0, n0, z, wm, wn, g, r16);
+  EpiPre<BM / 2 / 16, BN / 2 / 16> e;
+  gemm_epi_preload<T, BM, BN, 2, 2>(p, m0, n0, z, wm, wn, g, r16, false, e);
+  gemm_epilogue<T, BM, BN>(p, acc, e, m0, n0, z, wm, wn, g, r16);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -336,7 +463,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
   constexpr int NW = WM * WN;
@@ -393,6 +520,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  EpiPre<MI, NI> epre;       // epilogue operands: issued before (= older than) every ring load
+  gemm_epi_preload<T, BM, BN, WM, WN>(p, m0, n0, z, wm, wn, g, r16, true, epre);
+
   constexpr int EPC = 16 / (int)sizeof(T);
   const int nk = p.K / (KCH * EPC);
 #pragma unroll
@@ -426,19 +556,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
         for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], af[mi]);
     }
   }
-  gemm_epilogue<T, BM, BN, WM, WN>(p, acc, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+  gemm_epilogue<T, BM, BN, WM, WN, HEAVY>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
-static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY>
+static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
   constexpr int lds = NST * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, WN>();
   static bool once = [] {
-    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH>), grid, dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY>), grid, dim3(64 * WM * WN), lds, s, a);
   return hipGetLastError();
+}
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
+static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
+  return gemm_act_is_heavy(a.act) ? gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true>(a, s)
+                                  : gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false>(a, s);
 }
 
 template <typename T, int BM, int BN>
@@ -478,13 +613,20 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case 10: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 64, 2, 4, 3, 16>(a, s); break;
     case 11: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3, 16>(a, s); break;
     case 12: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 128, 2, 4, 3, 16>(a, s); break;
+    case 15: return gemm_glds_launch_t<T, 96, 128, 2, 2, 4>(a, s);    // 4 waves, 48x64 per wave
+    case 16: return gemm_glds_launch_t<T, 96, 128, 2, 2, 3>(a, s);
+    case 17: return gemm_glds_launch_t<T, 96, 64, 2, 2, 4>(a, s);     // 4 waves, 48x32 per wave
+    case 18: return gemm_glds_launch_t<T, 64, 128, 2, 2, 4>(a, s);    // 4 waves, 32x64 per wave
+    case 19: return gemm_glds_launch_t<T, 128, 128, 2, 2, 4>(a, s);   // 4 waves, 64x64 per wave, 4 stages (128 KB)
     default: break;
   }
   // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;
   // below that the 64x64 tile's extra blocks beat its higher L2->LDS traffic.
   const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
-  if (t128 >= 512) return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
-  if (t128x64 >= 700) return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);  // 8 waves, 32x32 per wave
+  static const long long thr128 = [] { const char* e = getenv("FDM_GEMM_T128"); return e ? atoll(e) : 512LL; }();
+  static const long long thr128x64 = [] { const char* e = getenv("FDM_GEMM_T128X64"); return e ? atoll(e) : 700LL; }();
+  if (t128 >= thr128) return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
+  if (t128x64 >= thr128x64) return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);  // 8 waves, 32x32 per wave
   return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                       // 8 waves, 32x16 per wave
 }
 
