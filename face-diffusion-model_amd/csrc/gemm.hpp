@@ -474,6 +474,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   static_assert(A_IPW >= 1 && W_IPW >= 1 && MI >= 1 && NI >= 1, "tile too small for the wave grid");
   constexpr int P = A_IPW + W_IPW;
   constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr bool EARLY_READS = (KCH / 4) * (MI + NI) <= 12;     // fragment registers for a whole k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
 
@@ -535,25 +536,52 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
     if (kt + NST - 2 < nk) wait_vmcnt<(NST - 2) * P>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();           // everyone's part of tile kt landed; stage (kt-1)%NST is free
-    if (kt + NST - 1 < nk) issue(kt + NST - 1);
     const char* base = smem + (kt % NST) * STAGE;
+    if constexpr (EARLY_READS) {
+      // fragment reads first, THEN the LDS-DMA issue for tile kt+NST-1: a DMA piece costs the issuing wave 60-180
+      // cycles (MI355X_MICROARCH.md) which now overlap the ds_read latency instead of preceding it (measured -3..-7 %).
+      // (Going further -- reading tile kt+1's fragments before tile kt's MFMAs, two register sets -- measured slower.)
+      u32x4 af[KCH / 4][MI], wf[KCH / 4][NI];
 #pragma unroll
-    for (int s = 0; s < KCH / 4; ++s) {
-      u32x4 af[MI], wf[NI];
+      for (int s = 0; s < KCH / 4; ++s) {
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        const int row = wm * (BM / WM) + mi * 16 + r16;
-        af[mi] = *(const u32x4*)(base + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row = wm * (BM / WM) + mi * 16 + r16;
+          af[s][mi] = *(const u32x4*)(base + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int row = wn * (BN / WN) + ni * 16 + r16;
+          wf[s][ni] = *(const u32x4*)(base + BM * ROWB + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+        }
       }
+      if (kt + NST - 1 < nk) issue(kt + NST - 1);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int row = wn * (BN / WN) + ni * 16 + r16;
-        wf[ni] = *(const u32x4*)(base + BM * ROWB + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+      for (int s = 0; s < KCH / 4; ++s)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[s][ni], af[s][mi]);
+    } else {
+      if (kt + NST - 1 < nk) issue(kt + NST - 1);
+#pragma unroll
+      for (int s = 0; s < KCH / 4; ++s) {
+        u32x4 af[MI], wf[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int row = wm * (BM / WM) + mi * 16 + r16;
+          af[mi] = *(const u32x4*)(base + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int row = wn * (BN / WN) + ni * 16 + r16;
+          wf[ni] = *(const u32x4*)(base + BM * ROWB + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], af[mi]);
       }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], af[mi]);
     }
   }
   gemm_epilogue<T, BM, BN, WM, WN, HEAVY>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
@@ -585,7 +613,8 @@ static hipError_t gemm_launch_t(const fdm_gemm_args& a, hipStream_t s) {
 }
 
 // Tile choice.  FDM_GEMM_VARIANT (env, read once) selects a kernel family for A/B measurements:
-//   0 = v1 register-staged double buffer (64x64 / 128x128), 1 = v2 LDS-DMA ring (default).
+//   0 = v1 register-staged double buffer (64x64 / 128x128), 1 = v2 LDS-DMA ring (default), 2..5 = ring with tile
+//   FDM_TILE_* = value - 1 forced for every GEMM.
 static int gemm_variant() {
   static int v = [] { const char* e = getenv("FDM_GEMM_VARIANT"); return e ? atoi(e) : 1; }();
   return v;
@@ -599,25 +628,12 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     if (a.stat_out || a.ln_stat_in) return hipErrorInvalidValue;      // LayerNorm folding lives in the ring kernels only
     return t128 >= 384 ? gemm_launch_t<T, 128, 128>(a, s) : gemm_launch_t<T, 64, 64>(a, s);
   }
-  switch (gemm_variant()) {
-    case 2: return gemm_glds_launch_t<T, 64, 64, 2, 2, 4>(a, s);     // 4 waves, 32x32 per wave
-    case 3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
-    case 4: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4>(a, s);    // 8 waves, 32x32 per wave
-    case 5: return gemm_glds_launch_t<T, 128, 128, 2, 2, 3>(a, s);   // 4 waves, 64x64 per wave
-    case 6: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
-    case 7: return gemm_glds_launch_t<T, 32, 64, 2, 2, 4>(a, s);     // 4 waves, 16x32 per wave
-    case 8: return gemm_glds_launch_t<T, 64, 64, 2, 2, 6>(a, s);     // deeper ring
-    case 13: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);    // 3 stages: 48 KB LDS -> 3 blocks per CU
-    case 14: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 2 stages: 32 KB LDS -> 5 blocks per CU
-    case 9: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 64, 2, 4, 4, 16>(a, s); break;   // 256-B rows
-    case 10: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 64, 2, 4, 3, 16>(a, s); break;
-    case 11: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3, 16>(a, s); break;
-    case 12: if (a.K % (256 / (int)sizeof(T)) == 0) return gemm_glds_launch_t<T, 64, 128, 2, 4, 3, 16>(a, s); break;
-    case 15: return gemm_glds_launch_t<T, 96, 128, 2, 2, 4>(a, s);    // 4 waves, 48x64 per wave
-    case 16: return gemm_glds_launch_t<T, 96, 128, 2, 2, 3>(a, s);
-    case 17: return gemm_glds_launch_t<T, 96, 64, 2, 2, 4>(a, s);     // 4 waves, 48x32 per wave
-    case 18: return gemm_glds_launch_t<T, 64, 128, 2, 2, 4>(a, s);    // 4 waves, 32x64 per wave
-    case 19: return gemm_glds_launch_t<T, 128, 128, 2, 2, 4>(a, s);   // 4 waves, 64x64 per wave, 4 stages (128 KB)
+  // explicit tile (fdm_gemm_args.tile, chosen by the caller's plan-time tuning) or the A/B override
+  switch (a.tile > 0 ? a.tile : (gemm_variant() > 1 ? gemm_variant() - 1 : 0)) {
+    case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);      // 8 waves, 32x16 per wave
+    case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
+    case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);  // 8 waves, 64x32 per wave
+    case FDM_TILE_96x128: return gemm_glds_launch_t<T, 96, 128, 2, 2, 4>(a, s);    // 4 waves, 48x64 per wave
     default: break;
   }
   // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;

@@ -26,7 +26,8 @@ import os
 import torch
 
 from . import ops, presets, schedule
-from ._lib import ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32, FdmError
+from ._lib import (ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32, TILE_64x64, TILE_96x128, TILE_128x64, TILE_128x128,
+                   FdmError)
 
 
 def _dev(t, device):
@@ -43,6 +44,7 @@ class DenoiserPlan:
         if p.head_dim not in (64, 128, 256):
             raise FdmError(f"denoiser head_dim {p.head_dim} unsupported (64, 128, 256)")
         self.stream = torch.cuda.Stream(device=dv)
+        self.tiles, self._tune_rec, self._tile_cache = {}, None, {}
         w = {k: _dev(v, dv) for k, v in weights.items() if not k.startswith("audio_encoder.") and k != "PE.pe"}
         self.w32 = w
         need = ["audio_extract.0.weight", "audio_extract.2.weight", "time_embedd.0.weight", "style_embedd.weight",
@@ -182,6 +184,7 @@ class DenoiserPlan:
                     else:
                         ops.add_rows(dst, Mc, d, self.pe, 1, L, sty[c * Bc:], L, Bc, e[c * Bc:], L, Bc)
             self._alloc_workspace()
+        self.tiles = dict(self._tile_cache.get((self.Rc, self.Mc, self.L, self.rep), {}))
         self.stream.synchronize()
         return L
 
@@ -206,6 +209,79 @@ class DenoiserPlan:
         self.tseq = torch.zeros(1024, dtype=torch.int32, device=dv)
 
     # ------------------------------------------------------------------------------------------
+    # ------------------------------------------------------------------------------------------
+    def _gemm(self, label, *a, **kw):
+        """One of the step's GEMM call sites; `label` keys the plan-time tile choice."""
+        if self._tune_rec is not None:
+            self._tune_rec.setdefault(label, []).append((a, dict(kw)))
+        ops.gemm(*a, tile=self.tiles.get(label, 0), **kw)
+
+    def _tune_tiles(self, n_steps=None):
+        """Time the candidate output tiles of every GEMM call site of the step at this plan's shapes and keep the
+        fastest.  Each candidate runs the call site's 8 per-layer instances (distinct weights, so they come from
+        beyond L2 as they do inside the step) as a replayed graph; ~50 ms in all, cached per shape, and only done for
+        chains long enough to repay it (n_steps >= 100, or n_steps=None to force).  Every tile accumulates k in the
+        same order, so the choice changes speed only, never results.  FDM_TUNE=0 keeps the library heuristic."""
+        key = (self.Rc, self.Mc, self.L, self.rep)
+        if os.environ.get("FDM_TUNE", "1") == "0" or key in self._tile_cache or (n_steps is not None and n_steps < 100):
+            return
+        self.tiles, self._tune_rec = {}, {}
+        with torch.cuda.stream(self.stream):
+            with ops.Program():            # dry recording of one chain: captures each call site's arguments, runs nothing
+                self._record_chain(0)
+            calls, self._tune_rec = self._tune_rec, None
+
+            def timed(inst, tile):
+                prog = ops.Program()
+                with prog:
+                    for a, kw in inst:
+                        ops.gemm(*a, tile=tile, **kw)
+                prog.instantiate()
+                prog.replay(2)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                prog.replay(5)
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1)
+
+            for label, inst in calls.items():
+                inst = [(a, {k: v for k, v in kw.items() if k != "incr_counter"}) for a, kw in inst]
+                while len(inst) < 4:
+                    inst = inst + inst
+                base = min(timed(inst, 0), timed(inst, 0))
+                best, best_t = 0, base * 0.97          # switch only for a > 3 % gain over the heuristic
+                for tile in (TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128):
+                    t = min(timed(inst, tile), timed(inst, tile))
+                    if t < best_t:
+                        best, best_t = tile, t
+                self.tiles[label] = best
+            # the isolated timings can mislead (cache state inside the step differs): keep the tuned set only if one
+            # whole denoiser pass of a clip group is faster with it than with the heuristic
+            tuned = dict(self.tiles)
+
+            def chain_time(tiles):
+                self.tiles = tiles
+                self.step.zero_()
+                prog = ops.Program()
+                with prog:
+                    self._record_chain(0)
+                prog.instantiate()
+                prog.replay(2)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                prog.replay(4)
+                e1.record()
+                e1.synchronize()
+                return e0.elapsed_time(e1)
+
+            if any(tuned.values()):
+                t_h = min(chain_time({}), chain_time({}))
+                t_t = min(chain_time(tuned), chain_time(tuned))
+                self.tiles = tuned if t_t < 0.995 * t_h else {}
+        self._tile_cache[key] = dict(self.tiles)
+        self._progs = {}                   # programs recorded with the old tiles are rebuilt
+
     def _record_chain(self, c):
         """Record the denoiser pass of clip group c: ws['x'] rows of the group -> ws['x0'] rows of the group."""
         p, d, ws, w, wt = self.p, self.p.d, self.ws, self.w32, self.wt
@@ -217,7 +293,7 @@ class DenoiserPlan:
         #  _load_x() before the first one)
         for r in range(self.rep):
             o = rb + r * Mc
-            ops.gemm(ws["xt"][xr:], wt["latent_encoder.0.weight"], Mc, d, d, bias=w["latent_encoder.0.bias"],
+            self._gemm("enc", ws["xt"][xr:], wt["latent_encoder.0.weight"], Mc, d, d, bias=w["latent_encoder.0.bias"],
                      act=ACT_MISH if p.latent_mish else ACT_NONE, resid=self.E0[o:], out_f32=ws["h"][o:],
                      out_t=ws["ht"][o:] if both else None,
                      incr_counter=step if r == 0 else None)      # first kernel of the step: step counter += 1
@@ -232,41 +308,42 @@ class DenoiserPlan:
             pre = f"transformer_decoder.layers.{l}."
             f = self.fold.get(l) if fuse else None
             if f is None:      # layer input h (fp32) / ht (operand copy) are materialised
-                ops.gemm(ws["ht"][rb:], wt[pre + "self_attn.in_proj_weight"], Rc, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"], **kv)
+                self._gemm("qkv", ws["ht"][rb:], wt[pre + "self_attn.in_proj_weight"], Rc, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"], **kv)
             else:              # layer input = LN3(x2) of the previous layer, never materialised
-                ops.gemm(ws["x2t"][rb:], f["w"], Rc, 3 * d, d, bias=f["bias"], **kv,
+                self._gemm("qkv_ln", ws["x2t"][rb:], f["w"], Rc, 3 * d, d, bias=f["bias"], **kv,
                          ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
             ops.attention(ws["q"][rb:], kp, vp, ws["ctx"][rb:], B=BBc, H=p.n_head, L=L, hd=p.head_dim,
                           ldq=d, ldo=d, Lpad=self.Lpad, scale=1.0 / math.sqrt(p.head_dim), causal=True,
                           slopes=self.slopes, period=p.period)
             if f is None:
-                ops.gemm(ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
-                         resid=ws["h"][rb:], out_f32=ws["x1"][rb:])
+                self._gemm("out", ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
+                           resid=ws["h"][rb:], out_f32=ws["x1"][rb:])
             else:
-                ops.gemm(ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
-                         resid=ws["x2"][rb:], out_f32=ws["x1"][rb:], ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps,
+                self._gemm("out_ln", ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
+                           resid=ws["x2"][rb:], out_f32=ws["x1"][rb:], ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps,
                          rln_gamma=f["gamma"], rln_beta=f["beta"])
             # norm1 and norm2 back to back in one kernel: h2 = LN2(LN1(x1) + C1_l + TT_l[t])
             ops.layernorm(ws["x1"][rb:], w[pre + "norm1.weight"], w[pre + "norm1.bias"], Rc, d, add_mat=self.C1[l][rb:],
                           add_tab=self.TT[l], tab_index=self.tseq, tab_step=step, y_f32=ws["h2"][rb:],
                           y_t=ws["h2t"][rb:] if both else None, dtype=self.dtype,
                           gamma2=w[pre + "norm2.weight"], beta2=w[pre + "norm2.bias"])
-            ops.gemm(ws["h2t"][rb:], wt[pre + "linear1.weight"], Rc, p.ffn, d, bias=w[pre + "linear1.bias"], act=ACT_RELU,
+            self._gemm("ffn1", ws["h2t"][rb:], wt[pre + "linear1.weight"], Rc, p.ffn, d, bias=w[pre + "linear1.bias"], act=ACT_RELU,
                      out_t=ws["u"][rb:])
             if fuse:           # x2 = h2 + FFN(h2): fp32 + operand copy + per-row partial sums for the folded norm3
+                # (producer of the folded-norm3 partial sums: their rounding order depends on the tile, so not tuned)
                 ops.gemm(ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
                          out_f32=ws["x2"][rb:], out_t=ws["x2t"][rb:], stat_out=st)
             else:
-                ops.gemm(ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
-                         out_f32=ws["x1"][rb:])
+                self._gemm("ffn2", ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
+                           out_f32=ws["x1"][rb:])
                 ops.layernorm(ws["x1"][rb:], w[pre + "norm3.weight"], w[pre + "norm3.bias"], Rc, d, y_f32=ws["h"][rb:],
                               y_t=ws["ht"][rb:] if both else None, dtype=self.dtype)
         if fuse:
             f = self.fold["dec"]
-            ops.gemm(ws["x2t"][rb:], f["w"], Rc, d, d, bias=f["bias"], out_f32=ws["x0"][rb:],
+            self._gemm("dec_ln", ws["x2t"][rb:], f["w"], Rc, d, d, bias=f["bias"], out_f32=ws["x0"][rb:],
                      ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
         else:
-            ops.gemm(ws["ht"][rb:], wt["latent_decoder.weight"], Rc, d, d, bias=w["latent_decoder.bias"], out_f32=ws["x0"][rb:])
+            self._gemm("dec", ws["ht"][rb:], wt["latent_decoder.weight"], Rc, d, d, bias=w["latent_decoder.bias"], out_f32=ws["x0"][rb:])
 
     def _program(self, kind, **kw):
         """Build (once) the step program `kind` in {'pass', 'ddpm', 'ddim'}: one lane per clip group."""
@@ -357,6 +434,7 @@ class DenoiserPlan:
         self._check_x(x_T)
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
+        self._tune_tiles(len(t_list))
         with torch.cuda.stream(self.stream):
             self._load_x(x_T)
             self._set_steps(list(t_list))
@@ -387,6 +465,7 @@ class DenoiserPlan:
         pairs, san, cn = self._ddim[steps]
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)
+        self._tune_tiles(len(pairs))
         with torch.cuda.stream(self.stream):
             self._load_x(x_T)
             self._set_steps([pr[0] for pr in pairs])

@@ -40,7 +40,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
          out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
          out_kp=None, kp_col0=0, out_vp=None, vp_col0=0, kv_L=0, kv_Lpad=0, kv_hd=0,
          stat_out=None, ln_stat_in=None, ln_nparts=0, ln_dim=0, ln_eps=1e-5, ln_colsum=None, rln_gamma=None, rln_beta=None,
-         incr_counter=None):
+         incr_counter=None, tile=0):
     a = GemmArgs()
     a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
     a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
@@ -57,6 +57,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.stat_out, a.ln_stat_in, a.ln_nparts, a.ln_dim, a.ln_eps = _p(stat_out), _p(ln_stat_in), ln_nparts, ln_dim, ln_eps
     a.ln_colsum, a.rln_gamma, a.rln_beta = _p(ln_colsum), _p(rln_gamma), _p(rln_beta)
     a.incr_counter = _p(incr_counter)
+    a.tile = tile
     check(lib().fdm_op_gemm(C.byref(a), stream()))
 
 

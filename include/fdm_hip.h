@@ -81,7 +81,15 @@ typedef struct fdm_gemm_args {
   /* optional device int incremented once (by one thread) when the kernel starts: the first GEMM of a diffusion
    * step advances the device-side step counter this way (no extra launch, no atomics on a hot word) */
   int* incr_counter;
+  /* output tile per workgroup: 0 = library heuristic, else FDM_TILE_*.  Results do not depend on it (every tile
+   * accumulates k in the same order): callers time the candidates once per shape at plan build and pass the winner. */
+  int tile;
 } fdm_gemm_args;
+#define FDM_TILE_AUTO 0
+#define FDM_TILE_64x64 1
+#define FDM_TILE_128x64 2
+#define FDM_TILE_128x128 3
+#define FDM_TILE_96x128 4
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -226,3 +226,31 @@ def test_full_size_cfg2_chain_properties():
     scale = float(outs[F32].abs().max())
     print(f"full-size cfg2: |fp32 - bf16| max-abs after 1000 steps = {d:.3e} (latent max {scale:.2f})")
     assert d < 0.25
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+def test_gemm_tile_choice_changes_speed_not_results(dtype, monkeypatch):
+    """Plan-time tile tuning (DenoiserPlan._tune_tiles): every output tile accumulates k in the same order, so forcing
+    any tile at every tuned call site gives bit-identical latents; FDM_TUNE=0 (library heuristic) likewise."""
+    from fdm_amd._lib import TILE_64x64, TILE_96x128, TILE_128x64, TILE_128x128
+    L, t = 70, 432
+    inp = W.synth_inputs("vocaset", 2, L, seed=5)
+    plan, _ = plan_for("vocaset", dtype)
+    plan.prepare(inp["hub"], inp["style"], L=L)
+    plan._tile_cache = {}
+    plan._tune_tiles()                 # forced (sampling calls tune lazily, for chains of >= 100 steps)
+    assert all(0 <= v <= 4 for v in plan.tiles.values())
+    plan.tiles = {k: 0 for k in ("enc", "qkv", "qkv_ln", "out", "out_ln", "ffn1", "ffn2", "dec", "dec_ln")}
+    base = plan.denoise(inp["x"].to(DEV), t).clone()
+    for tile in (TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128):
+        plan.tiles = {k: tile for k in plan.tiles}
+        plan._progs = {}
+        assert torch.equal(plan.denoise(inp["x"].to(DEV), t), base), f"tile {tile}"
+    monkeypatch.setenv("FDM_TUNE", "0")
+    plan._tile_cache = {}
+    plan.prepare(inp["hub"], inp["style"], L=L)
+    plan._tune_tiles()
+    assert plan.tiles == {}
+    assert torch.equal(plan.denoise(inp["x"].to(DEV), t), base)
+    monkeypatch.delenv("FDM_TUNE")
+    plan._tile_cache = {}

@@ -1,6 +1,6 @@
 """Micro-benchmark of the step's kernels at cfg2 shapes (M = 800, d = 1024) -- run on the GPU box.
 Each op is recorded into a Program 20x and replayed as a hipGraph; time = HIP events / launches."""
-import sys, math, torch
+import os, sys, math, torch
 sys.path.insert(0, 'face-diffusion-model_amd')
 from fdm_amd import ops
 from fdm_amd._lib import *
