@@ -10,7 +10,10 @@ namespace fdm {
 // ------------------------------------------------------------------------------------------------
 // LayerNorm: one wavefront per row, row held in registers (d = 256 * NV), two-pass statistics.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NV>
+// HEAVY: the output activation may be a transcendental one (GELU after HuBERT's conv LayerNorm).  The step's LayerNorms
+// are built without: the inlined libm activations x 16 elements per lane were 90 % of this kernel's code, and code size
+// is fixed cost per launch (profiles/README.md).
+template <typename T, int NV, bool HEAVY>
 __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -84,9 +87,12 @@ __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
     f32x4 gm = *(const f32x4*)(gam + col);
     f32x4 bt = *(const f32x4*)(bet + col);
     f32x4 y = v[i] * rstd * gm + bt;
-    if (p.act != ACT_NONE) {
+    if constexpr (HEAVY) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) y[j] = act_apply(y[j], p.act);
+    } else if (p.act == ACT_RELU) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
     }
     if (p.y_f32) *(f32x4*)(p.y_f32 + (size_t)row * d + col) = y;
     if (p.y_t) {
@@ -101,17 +107,21 @@ __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
   }
 }
 
-template <typename T>
-static hipError_t ln_launch_t(const fdm_ln_args& a, hipStream_t s) {
+template <typename T, bool HEAVY>
+static hipError_t ln_launch_h(const fdm_ln_args& a, hipStream_t s) {
   dim3 grid((a.M + 3) / 4), block(256);
   switch (a.d) {
-    case 256: hipLaunchKernelGGL((ln_kernel<T, 1>), grid, block, 0, s, a); break;
-    case 512: hipLaunchKernelGGL((ln_kernel<T, 2>), grid, block, 0, s, a); break;
-    case 768: hipLaunchKernelGGL((ln_kernel<T, 3>), grid, block, 0, s, a); break;
-    case 1024: hipLaunchKernelGGL((ln_kernel<T, 4>), grid, block, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((ln_kernel<T, 1, HEAVY>), grid, block, 0, s, a); break;
+    case 512: hipLaunchKernelGGL((ln_kernel<T, 2, HEAVY>), grid, block, 0, s, a); break;
+    case 768: hipLaunchKernelGGL((ln_kernel<T, 3, HEAVY>), grid, block, 0, s, a); break;
+    case 1024: hipLaunchKernelGGL((ln_kernel<T, 4, HEAVY>), grid, block, 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+template <typename T>
+static hipError_t ln_launch_t(const fdm_ln_args& a, hipStream_t s) {
+  return (a.act != ACT_NONE && a.act != ACT_RELU) ? ln_launch_h<T, true>(a, s) : ln_launch_h<T, false>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -92,9 +92,23 @@ __device__ __forceinline__ void gemm_epi_preload(const fdm_gemm_args& p, int m0,
 
 // HEAVY = the activation may be one of the transcendental ones (Mish, GELU): their libm expansions are hundreds of
 // instructions per element, so kernels for the plain / ReLU / LeakyReLU GEMMs (33 of the step's 34) are built without.
-template <bool HEAVY> __device__ __forceinline__ float gemm_act(float v, int act) {
-  if constexpr (HEAVY) return act_apply(v, act);
-  else return act == ACT_RELU ? fmaxf(v, 0.f) : (act == ACT_LEAKY02 ? (v > 0.f ? v : 0.2f * v) : v);
+template <bool HEAVY, typename T> __device__ __forceinline__ float gemm_act(float v, int act) {
+  if constexpr (!HEAVY) {
+    return act == ACT_RELU ? fmaxf(v, 0.f) : (act == ACT_LEAKY02 ? (v > 0.f ? v : 0.2f * v) : v);
+  } else if constexpr (sizeof(T) == 2) {
+    // bf16 (throughput) mode: hardware exp / log forms, ~1e-6 relative -- far inside the bf16 operand rounding
+    if (act == ACT_MISH) {
+      const float sp = v > 20.f ? v : __logf(1.f + __expf(v));
+      return v * (1.f - 2.f / (1.f + __expf(2.f * sp)));
+    }
+    if (act == ACT_GELU_TANH) {
+      const float c = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+      return v * (0.5f * (2.f - 2.f / (1.f + __expf(2.f * c))));
+    }
+    return act_apply(v, act);
+  } else {
+    return act_apply(v, act);     // fp32 (parity) mode: accurate libm forms
+  }
 }
 __host__ __device__ inline bool gemm_act_is_heavy(int act) { return act == ACT_MISH || act == ACT_GELU_ERF || act == ACT_GELU_TANH; }
 
@@ -162,7 +176,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         if (bias) v += bv[ni];
         if (p.act != ACT_NONE) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = gemm_act<HEAVY>(v[j], p.act);
+          for (int j = 0; j < 4; ++j) v[j] = gemm_act<HEAVY, T>(v[j], p.act);
         }
         if (p.resid) v += pre_rln ? (rv[mi][ni] - mu) * rs * gmv[ni] + btv[ni] : rv[mi][ni];
         if (do_stat) {
@@ -240,7 +254,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       }
       if (p.act != ACT_NONE) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gemm_act<HEAVY>(v[j], p.act);
+        for (int j = 0; j < 4; ++j) v[j] = gemm_act<HEAVY, T>(v[j], p.act);
       }
       if (p.resid) {
         const float* rp = p.resid + ocol + rrow * p.ldr + n;
@@ -361,7 +375,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const fdm_gemm_args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *p.incr_counter += 1;
+  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    const int nv = *p.incr_counter + 1;
+    *p.incr_counter = nv;
+    if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
+  }
   const int wm = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, r16 = lane & 15;
   const int z = blockIdx.z;
@@ -479,7 +497,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
 
   const int tid = threadIdx.x, lane = tid & 63;
-  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) *p.incr_counter += 1;
+  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    const int nv = *p.incr_counter + 1;
+    *p.incr_counter = nv;
+    if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r16 = lane & 15;

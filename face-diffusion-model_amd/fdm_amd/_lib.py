@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("out_kp", vp), ("kp_col0", ci), ("out_vp", vp), ("vp_col0", ci),
                 ("kv_L", ci), ("kv_Lpad", ci), ("kv_hd", ci),
                 ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
-                ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("tile", ci)]
+                ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci)]
 
 
 TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128 = 0, 1, 2, 3, 4

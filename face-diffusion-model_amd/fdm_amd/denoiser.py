@@ -205,7 +205,8 @@ class DenoiserPlan:
                   kp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=td),
                   vp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=td))
         self.ws = ws
-        self.step = torch.zeros(self.chains, dtype=torch.int32, device=dv)      # one device-side step counter per chain
+        # per chain: [device-side step counter, t of the current step]; both written by one thread of the step's first GEMM
+        self.step = torch.zeros(2 * self.chains, dtype=torch.int32, device=dv)
         self.tseq = torch.zeros(1024, dtype=torch.int32, device=dv)
 
     # ------------------------------------------------------------------------------------------
@@ -288,7 +289,7 @@ class DenoiserPlan:
         Mc, Rc, Bc, L = self.Mc, self.Rc, self.Bc, self.L
         xr, rb = c * Mc, c * Rc                         # first row of the group in x / in the decoder-stack buffers
         both = self.dtype == BF16
-        step = self.step[c:]
+        step, tcur = self.step[2 * c:], self.step[2 * c + 1:]
         # (the operand-dtype copy ws['xt'] of x is written by the scheduler kernel of the previous step and by
         #  _load_x() before the first one)
         for r in range(self.rep):
@@ -296,7 +297,8 @@ class DenoiserPlan:
             self._gemm("enc", ws["xt"][xr:], wt["latent_encoder.0.weight"], Mc, d, d, bias=w["latent_encoder.0.bias"],
                      act=ACT_MISH if p.latent_mish else ACT_NONE, resid=self.E0[o:], out_f32=ws["h"][o:],
                      out_t=ws["ht"][o:] if both else None,
-                     incr_counter=step if r == 0 else None)      # first kernel of the step: step counter += 1
+                     incr_counter=step if r == 0 else None, incr_table=self.tseq if r == 0 else None)
+            # (first kernel of the step: step counter += 1, tcur = tseq[step])
         BBc = Bc * self.rep
         kp, vp = ws["kp"][c * BBc * p.n_head:], ws["vp"][c * BBc * p.n_head:]
         kv = dict(out_t=ws["q"][rb:], ldo_t=d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=self.Lpad,
@@ -324,7 +326,7 @@ class DenoiserPlan:
                          rln_gamma=f["gamma"], rln_beta=f["beta"])
             # norm1 and norm2 back to back in one kernel: h2 = LN2(LN1(x1) + C1_l + TT_l[t])
             ops.layernorm(ws["x1"][rb:], w[pre + "norm1.weight"], w[pre + "norm1.bias"], Rc, d, add_mat=self.C1[l][rb:],
-                          add_tab=self.TT[l], tab_index=self.tseq, tab_step=step, y_f32=ws["h2"][rb:],
+                          add_tab=self.TT[l], tab_index=None, tab_step=tcur, y_f32=ws["h2"][rb:],
                           y_t=ws["h2t"][rb:] if both else None, dtype=self.dtype,
                           gamma2=w[pre + "norm2.weight"], beta2=w[pre + "norm2.bias"])
             self._gemm("ffn1", ws["h2t"][rb:], wt[pre + "linear1.weight"], Rc, p.ffn, d, bias=w[pre + "linear1.bias"], act=ACT_RELU,
@@ -361,7 +363,7 @@ class DenoiserPlan:
                 x0u = ws["x0"][c * Rc + Mc:] if self.cfg else None
                 x = ws["x"][c * Mc:]
                 xt = ws["xt"][c * Mc:] if self.dtype == BF16 else None
-                step = self.step[c:]
+                step = self.step[2 * c:]
                 if kind == "ddpm":
                     nz = kw.get("noise")
                     ops.sched_step(0, x0, x, x, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),

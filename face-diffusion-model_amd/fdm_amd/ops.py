@@ -40,7 +40,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
          out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
          out_kp=None, kp_col0=0, out_vp=None, vp_col0=0, kv_L=0, kv_Lpad=0, kv_hd=0,
          stat_out=None, ln_stat_in=None, ln_nparts=0, ln_dim=0, ln_eps=1e-5, ln_colsum=None, rln_gamma=None, rln_beta=None,
-         incr_counter=None, tile=0):
+         incr_counter=None, incr_table=None, tile=0):
     a = GemmArgs()
     a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
     a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
@@ -56,7 +56,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.kv_L, a.kv_Lpad, a.kv_hd = kv_L, kv_Lpad, kv_hd
     a.stat_out, a.ln_stat_in, a.ln_nparts, a.ln_dim, a.ln_eps = _p(stat_out), _p(ln_stat_in), ln_nparts, ln_dim, ln_eps
     a.ln_colsum, a.rln_gamma, a.rln_beta = _p(ln_colsum), _p(rln_gamma), _p(rln_beta)
-    a.incr_counter = _p(incr_counter)
+    a.incr_counter, a.incr_table = _p(incr_counter), _p(incr_table)
     a.tile = tile
     check(lib().fdm_op_gemm(C.byref(a), stream()))
 

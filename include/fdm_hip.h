@@ -81,6 +81,7 @@ typedef struct fdm_gemm_args {
   /* optional device int incremented once (by one thread) when the kernel starts: the first GEMM of a diffusion
    * step advances the device-side step counter this way (no extra launch, no atomics on a hot word) */
   int* incr_counter;
+  const int* incr_table;          /* optional: incr_counter[1] = incr_table[new counter value] (t = tseq[step] for the step) */
   /* output tile per workgroup: 0 = library heuristic, else FDM_TILE_*.  Results do not depend on it (every tile
    * accumulates k in the same order): callers time the candidates once per shape at plan build and pass the winner. */
   int tile;
