@@ -48,9 +48,17 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, r16 = lane & 15;
-  const int h = blockIdx.y, b = blockIdx.z;
+  // XCD-aware 1-D launch: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so the id is
+  // decoded such that all query tiles of one (clip, head) land on ONE XCD -- its K / V block is then fetched into one
+  // L2 instead of eight (FETCH_SIZE showed ~2.3x the algorithmic bytes with the plain (tile, head, clip) grid) -- and
+  // the longest (last, causal) query tiles are dispatched first.
   const int L = p.L;
-  const int q0 = blockIdx.x * BQ;
+  const int nqt = (L + BQ - 1) / BQ;
+  const int grp = blockIdx.x / (8 * nqt), rem = blockIdx.x % (8 * nqt);
+  const int bh = grp * 8 + (rem & 7);
+  if (bh >= p.B * p.H) return;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = (nqt - 1 - (rem >> 3)) * BQ;
   __shared__ __attribute__((aligned(16))) float part_o[4][BQ][HD];
   __shared__ float part_m[4][BQ], part_l[4][BQ];
 
@@ -246,16 +254,17 @@ static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   // than the number of workgroups; head_dim 256 keeps one (register budget)
   static const int dbg = getenv("FDM_ATTN_DBG") ? atoi(getenv("FDM_ATTN_DBG")) : 0;
   static const int qs2 = getenv("FDM_ATTN_QS2") ? atoi(getenv("FDM_ATTN_QS2")) : 384;
+  const int groups = (a.B * a.H + 7) / 8 * 8;        // (clip, head) pairs padded to whole XCD rounds
   if (HD == 128 && sizeof(T) == 2 && dbg) {
-    dim3 grid((a.L + 15) / 16, a.H, a.B);
+    dim3 grid((a.L + 15) / 16 * groups);
     hipLaunchKernelGGL((attn_kernel<T, HD, 1, (HD == 128 && sizeof(T) == 2) ? 2 : 0>), grid, dim3(256), 0, s, a);
     return;
   }
   if (HD <= 128 && a.L >= qs2) {
-    dim3 grid((a.L + 31) / 32, a.H, a.B);
+    dim3 grid((a.L + 31) / 32 * groups);
     hipLaunchKernelGGL((attn_kernel<T, HD, (HD <= 128 ? 2 : 1)>), grid, dim3(256), 0, s, a);
   } else {
-    dim3 grid((a.L + 15) / 16, a.H, a.B);
+    dim3 grid((a.L + 15) / 16 * groups);
     hipLaunchKernelGGL((attn_kernel<T, HD, 1>), grid, dim3(256), 0, s, a);
   }
 }
