@@ -2,6 +2,7 @@
 // Wavefront = 64 lanes; MFMA fragments are expressed as 16-byte lane chunks so that the bf16
 // (v_mfma_f32_16x16x32_bf16) and exact-fp32 (v_mfma_f32_16x16x4_f32) paths share one kernel body.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -58,10 +59,24 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// Sum over the 64 lanes, result in every lane.  Four DPP adds (quad swaps, half-row and row mirrors: VALU, a few cycles
+// each) give every lane its 16-lane row sum; the four row sums are combined through v_readlane.  The butterfly of
+// __shfl_xor it replaces is six dependent ds_bpermute round trips through the LDS crossbar (~0.25 us per reduction,
+// and the fused LN1+LN2 kernel chains four of them).
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  auto dpp_add = [](float x, auto ctrl) {
+    return x + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xF, 0xF, true));
+  };
+  v = dpp_add(v, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+  v = dpp_add(v, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+  v = dpp_add(v, std::integral_constant<int, 0x141>{});     // row_half_mirror
+  v = dpp_add(v, std::integral_constant<int, 0x140>{});     // row_mirror
+  const int vi = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
+  return (r0 + r1) + (r2 + r3);
 }
 
 
