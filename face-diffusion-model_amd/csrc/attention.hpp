@@ -170,8 +170,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
       for (int s = 0; s < NSUB; ++s)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[s][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows_max(mx);
       const float m_new = fmaxf(m_run[u], mx);
       const float alpha = fexp<T>(m_run[u] - m_new);
       float psum = 0.f;
@@ -208,8 +207,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
 #pragma unroll
   for (int u = 0; u < QS; ++u) {
     float l_tot = l_part[u];
-    l_tot += __shfl_xor(l_tot, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
+    l_tot = rows_sum(l_tot);
     if (g == 0) { part_m[wave][16 * u + r16] = m_run[u]; part_l[wave][16 * u + r16] = l_tot; }
 #pragma unroll
     for (int c = 0; c < NC; ++c) *(f32x4*)&part_o[wave][16 * u + r16][c * 16 + 4 * g] = o[u][c];

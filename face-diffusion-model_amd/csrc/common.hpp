@@ -59,6 +59,18 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// Reductions across the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48).  (gfx950's v_permlane16_swap /
+// v_permlane32_swap would do this in VALU, but neither the builtin nor inline asm gave the documented pair of results
+// in a probe on this toolchain, so these stay on the ds_bpermute path.)
+__device__ __forceinline__ float rows_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float rows_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
 // Sum over the 64 lanes, result in every lane.  Four DPP adds (quad swaps, half-row and row mirrors: VALU, a few cycles
 // each) give every lane its 16-lane row sum; the four row sums are combined through v_readlane.  The butterfly of
 // __shfl_xor it replaces is six dependent ds_bpermute round trips through the LDS crossbar (~0.25 us per reduction,

@@ -214,8 +214,8 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         }
       }
       if (do_stat) {
-        ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
-        pq += __shfl_xor(pq, 16, 64); pq += __shfl_xor(pq, 32, 64);
+        ps = rows_sum(ps);
+        pq = rows_sum(pq);
         if (g == 0) { comb[(wn * BM + lrow) * 2] = ps; comb[(wn * BM + lrow) * 2 + 1] = pq; }
       }
     }
@@ -332,8 +332,8 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       }
     }
     if (do_stat) {     // the 4 lane groups of a row hold disjoint columns: fold them, one lane stores the wave's partial
-      ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
-      pq += __shfl_xor(pq, 16, 64); pq += __shfl_xor(pq, 32, 64);
+      ps = rows_sum(ps);
+      pq = rows_sum(pq);
       if (g == 0) { comb[(wn * BM + lrow) * 2] = ps; comb[(wn * BM + lrow) * 2 + 1] = pq; }
     }
   }
