@@ -207,6 +207,15 @@ def main():
         fl = step_flops(p, B, L, cfg)
         step_ms = ev_ms / n_launch
         ach = fl / (step_ms * 1e-3) / 1e12
+        # HBM-side bytes per launch of the step graph: measured offline with rocprofv3 --pmc (bench.py cannot collect PMC
+        # counters on itself); taken from the committed summary when it was measured on this config, else null
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_summary.json")))
+            if pm.get("config") == a.config and pm.get("dtype") == a.dtype:
+                traffic = pm["traffic"]
+        except (OSError, ValueError, KeyError):
+            pass
         res = {
             "metric": "animated frames/sec (1000-step DDPM, VOCASET FDM) at 1/2/4/8 MI355X",
             "value": round(world * B * L * a.steps / el, 3), "unit": "frames/s",
@@ -220,7 +229,7 @@ def main():
             "diffusion_steps_per_s": round(n_launch / (ev_ms * 1e-3), 1),
             "roofline": {"bound": "mfma", "kernel": "denoiser step graph (one diffusion step, all kernels)",
                          "achieved": round(ach, 2), "peak": PEAK[a.dtype], "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK[a.dtype], 4), "traffic": None,
+                         "frac": round(ach / PEAK[a.dtype], 4), "traffic": traffic,
                          "flops_per_launch": fl, "avg_launch_ms": round(step_ms, 5)},
         }
         if not a.no_cpu_baseline and world == 1:
