@@ -47,6 +47,27 @@ def test_argument_validation_without_device():
     assert l.fdm_op_attention(C.byref(at), None) == -2
 
 
+def test_argument_validation_of_the_round1_additions():
+    """pack_kv / packed K,V outputs / tile / metrics / interpolation: bad arguments are reported, nothing is launched."""
+    from fdm_amd import _lib
+    l = _lib.lib()
+    assert l.fdm_op_pack_kv(16, 64, 16, 64, 16, 16, 1, 1, 10, 31, 64, _lib.BF16, None) == -2       # Lpad % 32
+    assert l.fdm_op_pack_kv(None, 64, 16, 64, 16, 16, 1, 1, 10, 32, 64, _lib.BF16, None) == -1
+    a = _lib.GemmArgs()
+    a.A, a.W, a.M, a.N, a.K, a.dtype, a.lda, a.ldw = 16, 16, 64, 192, 64, _lib.BF16, 64, 64
+    a.out_t, a.out_kp, a.kp_col0, a.out_vp, a.vp_col0 = 16, 16, 64, 16, 128
+    a.kv_L, a.kv_Lpad, a.kv_hd = 32, 32, 24                                                       # hd % 16
+    assert l.fdm_op_gemm(C.byref(a), None) == -2 and b"packed K/V" in l.fdm_last_error()
+    a.kv_hd, a.kv_L = 64, 48                                                                      # M % L
+    assert l.fdm_op_gemm(C.byref(a), None) == -2
+    a.out_kp = a.out_vp = None
+    a.tile = 9
+    assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"tile" in l.fdm_last_error()
+    assert l.fdm_op_vertex_err(16, 16, None, 5, 3, 10, 16, 16, 16, None) == -2                    # region NULL needs R == V
+    assert l.fdm_op_motion_std(16, None, None, 10, 3, 10, 16, 16, None) == -1
+    assert l.fdm_op_linear_interp(16, 16, 1, 0, 5, 4, None) == -1
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from fdm_amd import _lib, ops
