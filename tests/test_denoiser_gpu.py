@@ -254,3 +254,35 @@ def test_gemm_tile_choice_changes_speed_not_results(dtype, monkeypatch):
     assert torch.equal(plan.denoise(inp["x"].to(DEV), t), base)
     monkeypatch.delenv("FDM_TUNE")
     plan._tile_cache = {}
+
+
+@pytest.mark.parametrize("preset,L", [("vocaset", 498), ("mead", 300), ("vocaset", 600)])
+def test_long_clip_single_step_vs_oracle(preset, L):
+    """Clip lengths of the end-to-end configs (10 s audio -> L = 498: 32-query attention workgroups, >= 16 key tiles;
+    cfg3's L = 300; the L = 600 limit of init_biased_mask) against the oracle, fp32 and bf16."""
+    inp = W.synth_inputs(preset, 1, L, seed=900 + L)
+    _, w = plan_for(preset, F32)
+    t = 321
+    ref = FO.fdm_forward(w, preset, inp["hub"], t, inp["x"], inp["style"], inp.get("emo"), folded=True)
+    for dt, tol in ((F32, TOL32), (BF16, TOLBF)):
+        plan, _ = plan_for(preset, dt)
+        plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+        assert mad(plan.denoise(inp["x"].to(DEV), t).cpu(), ref) < tol, (preset, L, dt)
+
+
+def test_full_length_mead_cfg_chain_properties():
+    """cfg3's shape class (MEAD, L = 300, classifier-free guidance: cond + uncond rows in one set of launches) through
+    size-independent properties: determinism, graph == eager, clip independence under CFG."""
+    B, L = 2, 300
+    inp = W.synth_inputs("mead", B, L, seed=3)
+    ts = list(range(999, 879, -1))                # 120 steps (>= 100: the plan tunes its tiles)
+    plan, _ = plan_for("mead", F32)
+    plan.prepare(inp["hub"], inp["style"], inp["emo"], L=L, cfg=True)
+    xT = inp["x"].to(DEV)
+    a = plan.sample_ddpm(xT, ts, seed=9, cfg_scale=2.5)
+    assert torch.equal(a, plan.sample_ddpm(xT, ts, seed=9, cfg_scale=2.5)) and torch.isfinite(a).all()
+    assert torch.equal(plan.sample_ddpm(xT, ts[:30], seed=9, cfg_scale=2.5, use_graph=False),
+                       plan.sample_ddpm(xT, ts[:30], seed=9, cfg_scale=2.5, use_graph=True))
+    plan.prepare(inp["hub"][1:], inp["style"][1:], inp["emo"][1:], L=L, cfg=True)
+    one = plan.sample_ddpm(xT[1:], ts, seed=9, clip0=1, cfg_scale=2.5)
+    assert torch.equal(one[0], a[1]), "clip result depends on the batch it was sampled in"
