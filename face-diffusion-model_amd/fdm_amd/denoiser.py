@@ -17,7 +17,7 @@ What runs where
       fused scheduler update (DDPM / DDIM, optional CFG mix, Philox or injected noise; also writes the
       operand-dtype copy of x_{t-1} for the next step); the device-side step counter is advanced by one
       thread of the step's first GEMM:
-      51 kernel launches per diffusion step; 43 in bf16 mode, where norm3 is folded into the QKV / out-proj /
+      59 kernel launches per diffusion step; 51 in bf16 mode, where norm3 is folded into the QKV / out-proj /
       latent-decoder GEMMs through per-row partial sums written by the FFN2 epilogue.
 torch only owns the device buffers and the stream."""
 import math

@@ -7,7 +7,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 n_steps = int(sys.argv[3]) if len(sys.argv) > 3 else 20
-per_step = int(sys.argv[4]) if len(sys.argv) > 4 else 43
+per_step = int(sys.argv[4]) if len(sys.argv) > 4 else 51
 rows = [r for r in csv.DictReader(open(src)) if "fdm" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Dispatch_Id"]))
 tail = rows[-n_steps * per_step:]
