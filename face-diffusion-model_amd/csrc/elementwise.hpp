@@ -160,8 +160,50 @@ __device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigne
 // Explicit _rn operations (no FMA contraction) so the fp32 result is bit-identical to the
 // reference's unfused torch expression order.
 // ------------------------------------------------------------------------------------------------
+// Per-step scalars of the update (k = step index, t = tseq[k]) and the update of 4 consecutive latent elements starting at
+// flat element e of the x buffer.  Shared by sched_kernel and by the GEMM epilogue's fused form (fdm_gemm_args.sched_fuse),
+// so both produce the same bits.
+struct SchedCoef { int k, t; float c1, c2, sg, sra, srm1, san, cn; };
+__device__ __forceinline__ SchedCoef sched_coef_load(const fdm_sched_args& p) {
+  SchedCoef c;
+  c.k = p.step ? *(volatile const int*)p.step : 0;
+  c.t = p.tseq ? p.tseq[c.k] : c.k;
+  c.c1 = c.c2 = c.sg = c.sra = c.san = c.cn = 0.f;
+  c.srm1 = 1.f;
+  if (p.mode == 0) { c.c1 = p.c1[c.t]; c.c2 = p.c2[c.t]; c.sg = p.sigma[c.t]; }
+  if (p.mode == 1) { c.sra = p.sra[c.t]; c.srm1 = p.srm1[c.t]; c.san = p.sqrt_an[c.k]; c.cn = p.c_n[c.k]; }
+  return c;
+}
+__device__ __forceinline__ f32x4 sched_update4(const fdm_sched_args& p, const SchedCoef& c, f32x4 x0, f32x4 x, long long e) {
+  f32x4 o;
+  if (p.mode == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(c.c1, x0[j]), __fmul_rn(c.c2, x[j]));
+    if (c.t > 0) {
+      f32x4 z;
+      if (p.noise) {
+        z = *(const f32x4*)(p.noise + (size_t)c.k * (p.noise_stride > 0 ? p.noise_stride : p.n) + e);
+      } else {
+        const int clip = (int)(e / p.n_per_clip);
+        z = philox_normal4(p.seed, (unsigned)((e - (long long)clip * p.n_per_clip) >> 2), (unsigned)c.k,
+                           (unsigned)(p.clip0 + clip));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(o[j], __fmul_rn(c.sg, z[j]));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(c.sra, x[j]), x0[j]), c.srm1);
+      o[j] = __fadd_rn(__fmul_rn(x0[j], c.san), __fmul_rn(c.cn, eps));
+    }
+  }
+  return o;
+}
+
 __global__ __launch_bounds__(256) void sched_kernel(const fdm_sched_args p) {
-  const int k = p.step ? *(volatile const int*)p.step : 0;
+  const SchedCoef c = sched_coef_load(p);
+  const int k = c.k;
   if (p.arrive && p.advance && threadIdx.x == 0) {
     // every block reads *step first, then takes a ticket; the block holding the last ticket knows all
     // reads are done and advances the counter (and re-arms the ticket word) -- no separate launch
@@ -171,11 +213,7 @@ __global__ __launch_bounds__(256) void sched_kernel(const fdm_sched_args p) {
       *p.step = k + 1;
     }
   }
-  const int t = p.tseq ? p.tseq[k] : k;
   const long long nq = p.n / 4;
-  float c1 = 0.f, c2 = 0.f, sg = 0.f, sra = 0.f, srm1 = 1.f, san = 0.f, cn = 0.f;
-  if (p.mode == 0) { c1 = p.c1[t]; c2 = p.c2[t]; sg = p.sigma[t]; }
-  if (p.mode == 1) { sra = p.sra[t]; srm1 = p.srm1[t]; san = p.sqrt_an[k]; cn = p.c_n[k]; }
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long long)gridDim.x * blockDim.x) {
     f32x4 x0 = *(const f32x4*)(p.x0 + 4 * i);
     if (p.x0u) {
@@ -188,29 +226,7 @@ __global__ __launch_bounds__(256) void sched_kernel(const fdm_sched_args p) {
       o = x0;
     } else {
       const f32x4 x = *(const f32x4*)(p.x + 4 * i);
-      if (p.mode == 0) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fmul_rn(c1, x0[j]), __fmul_rn(c2, x[j]));
-        if (t > 0) {
-          f32x4 z;
-          if (p.noise) {
-            z = *(const f32x4*)(p.noise + (size_t)k * (p.noise_stride > 0 ? p.noise_stride : p.n) + 4 * i);
-          } else {
-            const long long e = 4 * i;
-            const int clip = (int)(e / p.n_per_clip);
-            z = philox_normal4(p.seed, (unsigned)((e - (long long)clip * p.n_per_clip) >> 2), (unsigned)k,
-                               (unsigned)(p.clip0 + clip));
-          }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(o[j], __fmul_rn(sg, z[j]));
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float eps = __fdiv_rn(__fsub_rn(__fmul_rn(sra, x[j]), x0[j]), srm1);
-          o[j] = __fadd_rn(__fmul_rn(x0[j], san), __fmul_rn(cn, eps));
-        }
-      }
+      o = sched_update4(p, c, x0, x, 4 * i);
     }
     *(f32x4*)(p.x_out + 4 * i) = o;
     if (p.x_out_t) {

@@ -88,6 +88,8 @@ int fdm_device_ok(void) {
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
+static bool gemm_act_heavy_host(int act) { return act == FDM_ACT_MISH || act == FDM_ACT_GELU_ERF || act == FDM_ACT_GELU_TANH; }
+
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W) return fail(FDM_ERR_ARG, "gemm: null operand");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return fail(FDM_ERR_SHAPE, "gemm: M,N,K must be positive (%d,%d,%d)", a->M, a->N, a->K);
@@ -111,6 +113,18 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (a->rln_gamma && (!a->rln_beta || !a->resid)) return fail(FDM_ERR_ARG, "gemm: rln_gamma needs rln_beta and resid");
   if ((a->stat_out || a->ln_stat_in) && (a->batch > 1 || a->out_batch_stride)) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding is not batched");
   if (a->tile < 0 || a->tile > FDM_TILE_96x128) return fail(FDM_ERR_ARG, "gemm: unknown tile %d", a->tile);
+  if (a->sched_fuse) {
+    const fdm_sched_args& sc = a->sched;
+    if (sc.mode != 0 && sc.mode != 1) return fail(FDM_ERR_ARG, "gemm: fused scheduler supports mode 0 (DDPM) and 1 (DDIM)");
+    if (!a->resid || !a->out_f32 || a->N % 64 || a->ldo_f32 != a->N || a->ldr != a->N || a->resid_row_mod || a->batch > 1 ||
+        !aligned16(a->resid) || !aligned16(a->out_f32) || (a->out_t && (a->ldo_t != a->N || !aligned16(a->out_t))))
+      return fail(FDM_ERR_SHAPE, "gemm: fused scheduler needs resid = x_t and out_f32 = x_{t-1} as dense [M, N] arrays, N %% 64 == 0");
+    if (gemm_act_heavy_host(a->act) || a->stat_out || a->out_kp || a->out_vp || a->rln_gamma)
+      return fail(FDM_ERR_ARG, "gemm: fused scheduler cannot be combined with Mish/GELU, stat_out, packed K/V or rln outputs");
+    if (sc.mode == 0 && (!sc.c1 || !sc.c2 || !sc.sigma)) return fail(FDM_ERR_ARG, "gemm: fused DDPM needs c1, c2, sigma");
+    if (sc.mode == 1 && (!sc.sra || !sc.srm1 || !sc.sqrt_an || !sc.c_n)) return fail(FDM_ERR_ARG, "gemm: fused DDIM needs sra, srm1, sqrt_an, c_n");
+    if (sc.mode == 0 && !sc.noise && sc.n_per_clip <= 0) return fail(FDM_ERR_ARG, "gemm: fused DDPM with Philox noise needs n_per_clip");
+  }
   fdm_gemm_args c = *a;
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
 }

@@ -60,12 +60,13 @@ __device__ __forceinline__ void gemm_load_rowstats(const fdm_gemm_args& p, int m
 // sit behind the stores of earlier fragments (the output pointers may alias the inputs as far as the compiler knows),
 // one exposed load latency per (mi, ni) fragment: measured 11 us of fixed cost on a 96x128 tile, ~1 us on 64x64.
 // Issued first, they are older than every ring load, so the k loop's counted vmcnt waits cover them too.
-template <int MI, int NI> struct EpiPre { f32x4 csv[NI], bv[NI], gmv[NI], btv[NI], rv[MI][NI]; };
+template <int MI, int NI> struct EpiPre { f32x4 csv[NI], bv[NI], gmv[NI], btv[NI], rv[MI][NI]; SchedCoef sc; };
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, bool SCHED = false>
 __device__ __forceinline__ void gemm_epi_preload(const fdm_gemm_args& p, int m0, int n0, int z, int wm, int wn, int g, int r16,
                                                  bool ln_capable, EpiPre<BM / WM / 16, BN / WN / 16>& e) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  if constexpr (SCHED) e.sc = sched_coef_load(p.sched);     // k -> t -> table entries: three dependent loads, hidden by the k loop
   const int M = p.M, N = p.N;
   const bool use_ln = ln_capable && p.ln_stat_in;
   const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
@@ -112,7 +113,7 @@ template <bool HEAVY, typename T> __device__ __forceinline__ float gemm_act(floa
 }
 __host__ __device__ inline bool gemm_act_is_heavy(int act) { return act == ACT_MISH || act == ACT_GELU_ERF || act == ACT_GELU_TANH; }
 
-template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true>
+template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true, bool SCHED = false>
 __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               const EpiPre<BM / WM / 16, BN / WN / 16>& e, int m0, int n0, int z,
                                               int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
@@ -178,7 +179,12 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = gemm_act<HEAVY, T>(v[j], p.act);
         }
-        if (p.resid) v += pre_rln ? (rv[mi][ni] - mu) * rs * gmv[ni] + btv[ni] : rv[mi][ni];
+        if constexpr (SCHED) {
+          // fused scheduler: v = x0_hat, rv = x_t (same element), flat element index of the chain's x buffer
+          v = sched_update4(p.sched, e.sc, v, rv[mi][ni], (long long)m * N + (ncol + ni * 16));
+        } else {
+          if (p.resid) v += pre_rln ? (rv[mi][ni] - mu) * rs * gmv[ni] + btv[ni] : rv[mi][ni];
+        }
         if (do_stat) {
           ps += (v[0] + v[1]) + (v[2] + v[3]);
           pq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
@@ -481,7 +487,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
   constexpr int NW = WM * WN;
@@ -544,7 +550,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   EpiPre<MI, NI> epre;       // epilogue operands: issued before (= older than) every ring load
-  gemm_epi_preload<T, BM, BN, WM, WN>(p, m0, n0, z, wm, wn, g, r16, true, epre);
+  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, true, epre);
 
   constexpr int EPC = 16 / (int)sizeof(T);
   const int nk = p.K / (KCH * EPC);
@@ -606,18 +612,18 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
       }
     }
   }
-  gemm_epilogue<T, BM, BN, WM, WN, HEAVY>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
   constexpr int lds = NST * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, WN>();
   static bool once = [] {
-    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY>), grid, dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED>), grid, dim3(64 * WM * WN), lds, s, a);
   return hipGetLastError();
 }
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
@@ -650,6 +656,7 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     if (a.stat_out || a.ln_stat_in) return hipErrorInvalidValue;      // LayerNorm folding lives in the ring kernels only
     return t128 >= 384 ? gemm_launch_t<T, 128, 128>(a, s) : gemm_launch_t<T, 64, 64>(a, s);
   }
+  if (a.sched_fuse) return gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true>(a, s);    // (validated: interior tiles only)
   // explicit tile (fdm_gemm_args.tile, chosen by the caller's plan-time tuning) or the A/B override
   switch (a.tile > 0 ? a.tile : (gemm_variant() > 1 ? gemm_variant() - 1 : 0)) {
     case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);      // 8 waves, 32x16 per wave

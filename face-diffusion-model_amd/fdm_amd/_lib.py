@@ -12,6 +12,15 @@ ACT_NONE, ACT_RELU, ACT_MISH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02 = range(6
 vp, ll, ci, cf = C.c_void_p, C.c_longlong, C.c_int, C.c_float
 
 
+class SchedArgs(C.Structure):
+    _fields_ = [("x0", vp), ("x0u", vp), ("cfg_scale", cf), ("x", vp), ("x_out", vp),
+                ("n", ll), ("n_per_clip", ll), ("tseq", vp), ("step", vp), ("advance", ci),
+                ("c1", vp), ("c2", vp), ("sigma", vp), ("sra", vp), ("srm1", vp),
+                ("sqrt_an", vp), ("c_n", vp), ("noise", vp), ("noise_stride", ll), ("x_out_t", vp), ("out_dtype", ci), ("arrive", vp),
+                ("seed", C.c_ulonglong), ("clip0", ci),
+                ("mode", ci)]
+
+
 class GemmArgs(C.Structure):
     _fields_ = [("A", vp), ("lda", ll), ("a_batch_stride", ll),
                 ("W", vp), ("ldw", ll), ("w_batch_stride", ll),
@@ -23,7 +32,8 @@ class GemmArgs(C.Structure):
                 ("out_kp", vp), ("kp_col0", ci), ("out_vp", vp), ("vp_col0", ci),
                 ("kv_L", ci), ("kv_Lpad", ci), ("kv_hd", ci),
                 ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
-                ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci)]
+                ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci),
+                ("sched_fuse", ci), ("sched", SchedArgs)]
 
 
 TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128 = 0, 1, 2, 3, 4
@@ -39,15 +49,6 @@ class LnArgs(C.Structure):
     _fields_ = [("x", vp), ("M", ci), ("d", ci), ("add_mat", vp), ("add_tab", vp),
                 ("tab_index", vp), ("tab_step", vp), ("gamma", vp), ("beta", vp), ("eps", cf),
                 ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci), ("gamma2", vp), ("beta2", vp)]
-
-
-class SchedArgs(C.Structure):
-    _fields_ = [("x0", vp), ("x0u", vp), ("cfg_scale", cf), ("x", vp), ("x_out", vp),
-                ("n", ll), ("n_per_clip", ll), ("tseq", vp), ("step", vp), ("advance", ci),
-                ("c1", vp), ("c2", vp), ("sigma", vp), ("sra", vp), ("srm1", vp),
-                ("sqrt_an", vp), ("c_n", vp), ("noise", vp), ("noise_stride", ll), ("x_out_t", vp), ("out_dtype", ci), ("arrive", vp),
-                ("seed", C.c_ulonglong), ("clip0", ci),
-                ("mode", ci)]
 
 
 # every symbol include/fdm_hip.h declares: name -> (restype, argtypes)

@@ -17,7 +17,8 @@ What runs where
       fused scheduler update (DDPM / DDIM, optional CFG mix, Philox or injected noise; also writes the
       operand-dtype copy of x_{t-1} for the next step); the device-side step counter is advanced by one
       thread of the step's first GEMM:
-      59 kernel launches per diffusion step; 51 in bf16 mode, where norm3 is folded into the QKV / out-proj /
+      59 kernel launches per diffusion step (58 without CFG: the scheduler update then runs in the latent decoder
+      GEMM's epilogue); 51 / 50 in bf16 mode, where norm3 is folded into the QKV / out-proj /
       latent-decoder GEMMs through per-row partial sums written by the FFN2 epilogue.
 torch only owns the device buffers and the stream."""
 import math
@@ -283,8 +284,10 @@ class DenoiserPlan:
         self._tile_cache[key] = dict(self.tiles)
         self._progs = {}                   # programs recorded with the old tiles are rebuilt
 
-    def _record_chain(self, c):
-        """Record the denoiser pass of clip group c: ws['x'] rows of the group -> ws['x0'] rows of the group."""
+    def _record_chain(self, c, sched=None):
+        """Record the denoiser pass of clip group c: ws['x'] rows of the group -> ws['x0'] rows of the group.
+        sched (fdm_sched_args, non-CFG samplers): the latent-decoder GEMM applies the scheduler update in its epilogue
+        and writes x_{t-1} straight into ws['x'] (+ its operand copy): x0 is not materialised, one launch less."""
         p, d, ws, w, wt = self.p, self.p.d, self.ws, self.w32, self.wt
         Mc, Rc, Bc, L = self.Mc, self.Rc, self.Bc, self.L
         xr, rb = c * Mc, c * Rc                         # first row of the group in x / in the decoder-stack buffers
@@ -340,12 +343,16 @@ class DenoiserPlan:
                            out_f32=ws["x1"][rb:])
                 ops.layernorm(ws["x1"][rb:], w[pre + "norm3.weight"], w[pre + "norm3.bias"], Rc, d, y_f32=ws["h"][rb:],
                               y_t=ws["ht"][rb:] if both else None, dtype=self.dtype)
+        if sched is not None:      # x_{t-1} = update(x0_hat = this GEMM, x_t = ws['x']) in the epilogue
+            out = dict(resid=ws["x"][xr:], out_f32=ws["x"][xr:], out_t=ws["xt"][xr:] if both else None, sched=sched)
+        else:
+            out = dict(out_f32=ws["x0"][rb:])
         if fuse:
             f = self.fold["dec"]
-            self._gemm("dec_ln", ws["x2t"][rb:], f["w"], Rc, d, d, bias=f["bias"], out_f32=ws["x0"][rb:],
-                     ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
+            self._gemm("dec_ln", ws["x2t"][rb:], f["w"], Rc, d, d, bias=f["bias"], **out,
+                       ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
         else:
-            self._gemm("dec", ws["ht"][rb:], wt["latent_decoder.weight"], Rc, d, d, bias=w["latent_decoder.bias"], out_f32=ws["x0"][rb:])
+            self._gemm("dec", ws["ht"][rb:], wt["latent_decoder.weight"], Rc, d, d, bias=w["latent_decoder.bias"], **out)
 
     def _program(self, kind, **kw):
         """Build (once) the step program `kind` in {'pass', 'ddpm', 'ddim'}: one lane per clip group."""
@@ -356,26 +363,35 @@ class DenoiserPlan:
         n = Mc * d
         prog = ops.Program()
         with prog:
+            fuse_sched = (not self.cfg) and kind in ("ddpm", "ddim") and os.environ.get("FDM_FUSE_SCHED", "1") != "0"
             for c in range(self.chains):
                 prog.lane(c)
-                self._record_chain(c)
                 x0 = ws["x0"][c * Rc:]
                 x0u = ws["x0"][c * Rc + Mc:] if self.cfg else None
                 x = ws["x"][c * Mc:]
                 xt = ws["xt"][c * Mc:] if self.dtype == BF16 else None
                 step = self.step[2 * c:]
+                skw = None
                 if kind == "ddpm":
                     nz = kw.get("noise")
-                    ops.sched_step(0, x0, x, x, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
-                                   n_per_clip=self.L * d, tseq=self.tseq, step=step, advance=0,
-                                   c1=self.c1, c2=self.c2, sigma=self.sigma,
-                                   noise=None if nz is None else nz.view(-1)[c * n:], noise_stride=self.M * d,
-                                   seed=kw.get("seed", 0), clip0=kw.get("clip0", 0) + c * self.Bc, x_out_t=xt)
+                    skw = dict(mode=0, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
+                               n_per_clip=self.L * d, tseq=self.tseq, step=step, advance=0,
+                               c1=self.c1, c2=self.c2, sigma=self.sigma,
+                               noise=None if nz is None else nz.view(-1)[c * n:], noise_stride=self.M * d,
+                               seed=kw.get("seed", 0), clip0=kw.get("clip0", 0) + c * self.Bc)
                 elif kind == "ddim":
-                    ops.sched_step(1, x0, x, x, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
-                                   tseq=self.tseq, step=step, advance=0, sra=self.buf["sqrt_recip_alphas_cumprod"],
-                                   srm1=self.buf["sqrt_recipm1_alphas_cumprod"], sqrt_an=kw["sqrt_an"], c_n=kw["c_n"],
-                                   x_out_t=xt)
+                    skw = dict(mode=1, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
+                               tseq=self.tseq, step=step, advance=0, sra=self.buf["sqrt_recip_alphas_cumprod"],
+                               srm1=self.buf["sqrt_recipm1_alphas_cumprod"], sqrt_an=kw["sqrt_an"], c_n=kw["c_n"])
+                if skw is not None and fuse_sched:
+                    # non-CFG samplers: the update runs in the latent decoder GEMM's epilogue (bit-identical, one launch less)
+                    mode = skw.pop("mode")
+                    self._record_chain(c, sched=ops.sched_args(mode, None, None, None, n, **skw))
+                    continue
+                self._record_chain(c)
+                if skw is not None:
+                    mode = skw.pop("mode")
+                    ops.sched_step(mode, x0, x, x, n, x_out_t=xt, **skw)
                 elif kind == "pass" and self.cfg:
                     ops.sched_step(2, x0, None, x0, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0))
         prog.hold(*[v for v in kw.values() if torch.is_tensor(v)])

@@ -40,7 +40,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
          out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
          out_kp=None, kp_col0=0, out_vp=None, vp_col0=0, kv_L=0, kv_Lpad=0, kv_hd=0,
          stat_out=None, ln_stat_in=None, ln_nparts=0, ln_dim=0, ln_eps=1e-5, ln_colsum=None, rln_gamma=None, rln_beta=None,
-         incr_counter=None, incr_table=None, tile=0):
+         incr_counter=None, incr_table=None, tile=0, sched=None):
     a = GemmArgs()
     a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
     a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
@@ -58,6 +58,8 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.ln_colsum, a.rln_gamma, a.rln_beta = _p(ln_colsum), _p(rln_gamma), _p(rln_beta)
     a.incr_counter, a.incr_table = _p(incr_counter), _p(incr_table)
     a.tile = tile
+    if sched is not None:      # fused scheduler update in the epilogue (resid = x_t, out_f32 = x_{t-1})
+        a.sched_fuse, a.sched = 1, sched
     check(lib().fdm_op_gemm(C.byref(a), stream()))
 
 
@@ -95,9 +97,10 @@ def layernorm(x, gamma, beta, M, d, *, add_mat=None, add_tab=None, tab_index=Non
     check(lib().fdm_op_layernorm(C.byref(a), stream()))
 
 
-def sched_step(mode, x0, x, x_out, n, *, x0u=None, cfg_scale=0.0, n_per_clip=0, tseq=None, step=None, advance=0,
+def sched_args(mode, x0, x, x_out, n, *, x0u=None, cfg_scale=0.0, n_per_clip=0, tseq=None, step=None, advance=0,
                c1=None, c2=None, sigma=None, sra=None, srm1=None, sqrt_an=None, c_n=None, noise=None, noise_stride=0,
                seed=0, clip0=0, x_out_t=None, arrive=None):
+    """fdm_sched_args for fdm_op_sched_step, or (with x0 / x / x_out None) for gemm(..., sched=...)."""
     a = SchedArgs()
     a.x0, a.x0u, a.cfg_scale, a.x, a.x_out = _p(x0), _p(x0u), cfg_scale, _p(x), _p(x_out)
     a.n, a.n_per_clip, a.tseq, a.step, a.advance = n, n_per_clip, _p(tseq), _p(step), advance
@@ -105,6 +108,11 @@ def sched_step(mode, x0, x, x_out, n, *, x0u=None, cfg_scale=0.0, n_per_clip=0, 
     a.sqrt_an, a.c_n, a.noise, a.noise_stride = _p(sqrt_an), _p(c_n), _p(noise), noise_stride
     a.seed, a.clip0, a.mode = seed, clip0, mode
     a.x_out_t, a.out_dtype, a.arrive = _p(x_out_t), (code_of(x_out_t) if x_out_t is not None else 0), _p(arrive)
+    return a
+
+
+def sched_step(mode, x0, x, x_out, n, **kw):
+    a = sched_args(mode, x0, x, x_out, n, **kw)
     check(lib().fdm_op_sched_step(C.byref(a), stream()))
 
 

@@ -43,6 +43,33 @@ int fdm_version(void);
 int fdm_device_ok(void);
 
 /* ------------------------------------------------------------------------------------------
+ * Scheduler (GaussianDiffusion.q_posterior + p_sample, ddim_sample update, CFG mix):
+ * video_diffusion_pytorch/diffusion_BIWI_encoder_decoder.py:632-656, 693-708;
+ * utiles/classifierfree.py:20-21.  All clips of the batch share the timestep (a3).
+ * tables are fp32 [T_train] arrays; the current step k = *step (device int, incremented by the
+ * kernel when advance != 0), t = tseq[k].  x0u != NULL enables the CFG mix
+ * x0 = x0u + cfg_scale*(x0 - x0u) before the update.
+ * DDPM: x' = c1[t]*x0 + c2[t]*x + sigma[t]*z, z = 0 when t == 0.  z comes from `noise`
+ * (+ k*n elements) if non-NULL, else Philox4x32-10/Box-Muller keyed by (seed, clip0 + clip, k).
+ * DDIM (eta = 0): eps = (sra[t]*x - x0)/srm1[t]; x' = x0*sqrt_an[k] + c_n[k]*eps.           */
+typedef struct fdm_sched_args {
+  const float* x0; const float* x0u; float cfg_scale;
+  const float* x; float* x_out;
+  long long n; long long n_per_clip;
+  const int* tseq; int* step; int advance;
+  const float* c1; const float* c2; const float* sigma;      /* DDPM tables, indexed by t */
+  const float* sra; const float* srm1;                       /* DDIM tables, indexed by t */
+  const float* sqrt_an; const float* c_n;                    /* DDIM tables, indexed by step k */
+  const float* noise; long long noise_stride;               /* elements between steps (0 -> n) */
+  void* x_out_t; int out_dtype;                              /* optional operand-dtype copy of x_out (next step's GEMM input) */
+  unsigned int* arrive;                                      /* device word (zeroed once): lets the LAST block to read *step
+                                                                advance it inside this kernel (no separate launch) */
+  unsigned long long seed; int clip0;
+  int mode;                                                  /* 0 DDPM, 1 DDIM, 2 CFG mix only (x_out = mix) */
+} fdm_sched_args;
+int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * C[M,N] = epilogue(A[M,K] * W[N,K]^T): every nn.Linear / Conv1d-as-GEMM on the path
  * (models/fdm_vocaset.py:20-24,36-39,45-51; transformers HubertAttention/FeedForward;
  * models/lib/base_models.py:71-87,138-174; models/vq_vae_vocaset.py:204,243).
@@ -85,6 +112,13 @@ typedef struct fdm_gemm_args {
   /* output tile per workgroup: 0 = library heuristic, else FDM_TILE_*.  Results do not depend on it (every tile
    * accumulates k in the same order): callers time the candidates once per shape at plan build and pass the winner. */
   int tile;
+  /* sched_fuse != 0: the epilogue applies fdm_op_sched_step's DDPM / DDIM update (sched.mode 0 / 1, no CFG mix) to the
+   * tile it just computed, v = x0_hat: `resid` is read as the current latent x_t (NOT added), and x_{t-1} goes to
+   * out_f32 (may alias resid) and, if given, out_t (the next step's operand copy).  The latent-decoder GEMM of a
+   * non-CFG sampler uses this: one launch less per diffusion step, bit-identical to the separate kernel.  Needs
+   * N % 64 == 0, ldo_f32 == ldr == N, 16-byte aligned pointers; sched.x0 / x0u / x / x_out / x_out_t / arrive unused. */
+  int sched_fuse;
+  fdm_sched_args sched;
 } fdm_gemm_args;
 #define FDM_TILE_AUTO 0
 #define FDM_TILE_64x64 1
@@ -147,32 +181,6 @@ typedef struct fdm_ln_args {
 } fdm_ln_args;
 int fdm_op_layernorm(const fdm_ln_args* a, void* stream);
 
-/* ------------------------------------------------------------------------------------------
- * Scheduler (GaussianDiffusion.q_posterior + p_sample, ddim_sample update, CFG mix):
- * video_diffusion_pytorch/diffusion_BIWI_encoder_decoder.py:632-656, 693-708;
- * utiles/classifierfree.py:20-21.  All clips of the batch share the timestep (a3).
- * tables are fp32 [T_train] arrays; the current step k = *step (device int, incremented by the
- * kernel when advance != 0), t = tseq[k].  x0u != NULL enables the CFG mix
- * x0 = x0u + cfg_scale*(x0 - x0u) before the update.
- * DDPM: x' = c1[t]*x0 + c2[t]*x + sigma[t]*z, z = 0 when t == 0.  z comes from `noise`
- * (+ k*n elements) if non-NULL, else Philox4x32-10/Box-Muller keyed by (seed, clip0 + clip, k).
- * DDIM (eta = 0): eps = (sra[t]*x - x0)/srm1[t]; x' = x0*sqrt_an[k] + c_n[k]*eps.           */
-typedef struct fdm_sched_args {
-  const float* x0; const float* x0u; float cfg_scale;
-  const float* x; float* x_out;
-  long long n; long long n_per_clip;
-  const int* tseq; int* step; int advance;
-  const float* c1; const float* c2; const float* sigma;      /* DDPM tables, indexed by t */
-  const float* sra; const float* srm1;                       /* DDIM tables, indexed by t */
-  const float* sqrt_an; const float* c_n;                    /* DDIM tables, indexed by step k */
-  const float* noise; long long noise_stride;               /* elements between steps (0 -> n) */
-  void* x_out_t; int out_dtype;                              /* optional operand-dtype copy of x_out (next step's GEMM input) */
-  unsigned int* arrive;                                      /* device word (zeroed once): lets the LAST block to read *step
-                                                                advance it inside this kernel (no separate launch) */
-  unsigned long long seed; int clip0;
-  int mode;                                                  /* 0 DDPM, 1 DDIM, 2 CFG mix only (x_out = mix) */
-} fdm_sched_args;
-int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Small elementwise / layout operators.                                                      */
