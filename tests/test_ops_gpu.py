@@ -423,3 +423,32 @@ def test_gemm_layernorm_folding(dtype, M, N):
              rln_gamma=gam.to(DEV), rln_beta=bet.to(DEV))
     torch.cuda.synchronize()
     assert rel(y2, ref2) < (3e-5 if dtype == F32 else 1e-2)
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gemm_fused_scheduler_equals_gemm_then_sched_step(dtype, mode):
+    """fdm_gemm_args.sched_fuse: the latent-decoder GEMM applying the DDPM (Philox noise) / DDIM update in its epilogue
+    writes the same bits as the GEMM followed by fdm_op_sched_step."""
+    g = torch.Generator().manual_seed(7 + mode)
+    td = ops.tdtype(dtype)
+    B, L, d, K = 3, 50, 256, 256
+    M = B * L
+    A = torch.randn(M, K, generator=g).to(td).to(DEV)
+    W = (torch.randn(d, K, generator=g) / math.sqrt(K)).to(td).to(DEV)
+    bias = torch.randn(d, generator=g).to(DEV)
+    x = torch.randn(M, d, generator=g).to(DEV)
+    tab = [(torch.rand(1000, generator=g) + 0.1).to(DEV) for _ in range(7)]
+    tseq = torch.tensor([999, 500, 0], dtype=torch.int32, device=DEV)
+    for k in range(3):
+        step = torch.tensor([k, 0], dtype=torch.int32, device=DEV)
+        kw = dict(n_per_clip=L * d, tseq=tseq, step=step, seed=99, clip0=4)
+        kw.update(dict(c1=tab[0], c2=tab[1], sigma=tab[2]) if mode == 0 else dict(sra=tab[3], srm1=tab[4], sqrt_an=tab[5], c_n=tab[6]))
+        x0 = torch.zeros(M, d, device=DEV)
+        ops.gemm(A, W, M, d, K, bias=bias, out_f32=x0)
+        ref, ref_t = torch.zeros(M, d, device=DEV), torch.zeros(M, d, device=DEV, dtype=td)
+        ops.sched_step(mode, x0, x, ref, M * d, x_out_t=ref_t, **kw)
+        xf, xf_t = x.clone(), torch.zeros(M, d, device=DEV, dtype=td)
+        ops.gemm(A, W, M, d, K, bias=bias, resid=xf, out_f32=xf, out_t=xf_t, sched=ops.sched_args(mode, None, None, None, M * d, **kw))
+        torch.cuda.synchronize()
+        assert torch.equal(xf, ref) and torch.equal(xf_t, ref_t), (mode, k)
