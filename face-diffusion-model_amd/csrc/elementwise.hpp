@@ -16,7 +16,7 @@ namespace fdm {
 template <typename T, int NV, bool HEAVY>
 __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= p.M) return;
   constexpr int d = 256 * NV;
   const float* xr = p.x + (size_t)row * d;
@@ -109,7 +109,11 @@ __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
 
 template <typename T, bool HEAVY>
 static hipError_t ln_launch_h(const fdm_ln_args& a, hipStream_t s) {
-  dim3 grid((a.M + 3) / 4), block(256);
+  // rows (= waves) per workgroup: 2 for the step's few-hundred-row LayerNorms, so the rows spread over all 256 CUs
+  // (800 rows / 4 = 200 workgroups left 56 CUs idle: measured +2.7 % end to end at cfg2, +0.5 % at cfg5), else 4
+  static const int rpb_env = [] { const char* e = getenv("FDM_LN_RPB"); return e ? atoi(e) : 0; }();
+  const int rpb = (rpb_env == 1 || rpb_env == 2 || rpb_env == 4) ? rpb_env : (a.M <= 4096 ? 2 : 4);
+  dim3 grid((a.M + rpb - 1) / rpb), block(64 * rpb);
   switch (a.d) {
     case 256: hipLaunchKernelGGL((ln_kernel<T, 1, HEAVY>), grid, block, 0, s, a); break;
     case 512: hipLaunchKernelGGL((ln_kernel<T, 2, HEAVY>), grid, block, 0, s, a); break;
