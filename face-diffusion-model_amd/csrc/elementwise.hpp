@@ -109,10 +109,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
 
 template <typename T, bool HEAVY>
 static hipError_t ln_launch_h(const fdm_ln_args& a, hipStream_t s) {
-  // rows (= waves) per workgroup: 2 for the step's few-hundred-row LayerNorms, so the rows spread over all 256 CUs
-  // (800 rows / 4 = 200 workgroups left 56 CUs idle: measured +2.7 % end to end at cfg2, +0.5 % at cfg5), else 4
+  // rows (= waves) per workgroup.  FDM_LN_RPB=1|2 spreads few-hundred-row LayerNorms over more CUs; alternating A/B runs
+  // at cfg2 (800 rows) showed no difference beyond the +-1 % run-to-run spread of the boxes, so 4 stays.
   static const int rpb_env = [] { const char* e = getenv("FDM_LN_RPB"); return e ? atoi(e) : 0; }();
-  const int rpb = (rpb_env == 1 || rpb_env == 2 || rpb_env == 4) ? rpb_env : (a.M <= 4096 ? 2 : 4);
+  const int rpb = (rpb_env == 1 || rpb_env == 2 || rpb_env == 4) ? rpb_env : 4;
   dim3 grid((a.M + rpb - 1) / rpb), block(64 * rpb);
   switch (a.d) {
     case 256: hipLaunchKernelGGL((ln_kernel<T, 1, HEAVY>), grid, block, 0, s, a); break;
