@@ -23,7 +23,8 @@ namespace fdm {
 
 // LDS scratch of the LayerNorm-folding epilogue: rowstat[BM][2] (mu, rstd of this block's rows) followed by
 // the cross-wave combine area [WN][BM][2]
-template <int BM, int WN> constexpr int gemm_ln_scratch_bytes() { return BM * 2 * (1 + WN) * 4; }
+// LayerNorm-folding scratch behind the ring: per-row (mu, rstd) + one (sum, sum of squares) pair per row and 16-column fragment
+template <int BM, int BN> constexpr int gemm_ln_scratch_bytes() { return BM * 2 * (1 + BN / 16) * 4; }
 
 // Consumer side: mu / rstd of the block's rows from the producer's per-64-column partial sums (fixed order).
 template <int BM>
@@ -160,7 +161,6 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       const int m = m0 + lrow;
       if (m >= M) continue;
       const float mu = use_ln ? rowstat[2 * lrow] : 0.f, rs = use_ln ? rowstat[2 * lrow + 1] : 1.f;
-      float ps = 0.f, pq = 0.f;
       float* o32 = p.out_f32 ? p.out_f32 + ocol + (size_t)m * p.ldo_f32 + ncol : nullptr;
       T* ot = p.out_t ? (T*)p.out_t + ocol + (size_t)m * p.ldo_t + ncol : nullptr;
       T* okp = nullptr;
@@ -185,9 +185,10 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         } else {
           if (p.resid) v += pre_rln ? (rv[mi][ni] - mu) * rs * gmv[ni] + btv[ni] : rv[mi][ni];
         }
-        if (do_stat) {
-          ps += (v[0] + v[1]) + (v[2] + v[3]);
-          pq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        if (do_stat) {      // canonical order (tile-independent): 4 columns per lane, 4 lane groups, then fragments in column order
+          const float fs = rows_sum((v[0] + v[1]) + (v[2] + v[3]));
+          const float fq = rows_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+          if (g == 0) { float* cb = comb + ((size_t)(wn * NI + ni) * BM + lrow) * 2; cb[0] = fs; cb[1] = fq; }
         }
         if (kv_mode == 2) {
           const int nl = wn * (BN / WN) + ni * 16 + 4 * g;
@@ -219,11 +220,6 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
           }
         }
       }
-      if (do_stat) {
-        ps = rows_sum(ps);
-        pq = rows_sum(pq);
-        if (g == 0) { comb[(wn * BM + lrow) * 2] = ps; comb[(wn * BM + lrow) * 2 + 1] = pq; }
-      }
     }
   } else {
 #pragma unroll
@@ -233,7 +229,6 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
     if (m >= M) continue;
     const size_t rrow = p.resid_row_mod > 0 ? (size_t)(m % p.resid_row_mod) : (size_t)m;
     const float mu = use_ln ? rowstat[2 * lrow] : 0.f, rs = use_ln ? rowstat[2 * lrow + 1] : 1.f;
-    float ps = 0.f, pq = 0.f;
     int kv_b = 0, kv_l = 0;
     if (p.out_kp || p.out_vp) { kv_b = m / p.kv_L; kv_l = m - kv_b * p.kv_L; }
 #pragma unroll
@@ -278,9 +273,12 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
             if (n + j < N) v[j] += rp[j];
         }
       }
-      if (do_stat) {
-        for (int j = 0; j < 4; ++j)
-          if (n + j < N) { ps += v[j]; pq += v[j] * v[j]; }
+      if (do_stat) {      // same canonical order as the lean path (columns past N contribute zeros)
+        float w4[4];
+        for (int j = 0; j < 4; ++j) w4[j] = (n + j < N) ? v[j] : 0.f;
+        const float fs = rows_sum((w4[0] + w4[1]) + (w4[2] + w4[3]));
+        const float fq = rows_sum((w4[0] * w4[0] + w4[1] * w4[1]) + (w4[2] * w4[2] + w4[3] * w4[3]));
+        if (g == 0) { float* cb = comb + ((size_t)(wn * NI + ni) * BM + lrow) * 2; cb[0] = fs; cb[1] = fq; }
       }
       if (vt_tile) {
         const int nl = wn * (BN / WN) + ni * 16 + 4 * g;
@@ -337,11 +335,6 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         }
       }
     }
-    if (do_stat) {     // the 4 lane groups of a row hold disjoint columns: fold them, one lane stores the wave's partial
-      ps = rows_sum(ps);
-      pq = rows_sum(pq);
-      if (g == 0) { comb[(wn * BM + lrow) * 2] = ps; comb[(wn * BM + lrow) * 2 + 1] = pq; }
-    }
   }
   }
   if (vt_tile) {
@@ -361,12 +354,17 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
     __syncthreads();
     const int t = threadIdx.x;
     if (t < BM && m0 + t < M) {
-      float s = 0.f, q = 0.f;
+      // one (sum, sum of squares) slot per 64-column group: its four 16-column fragments in column order, whatever the
+      // tile / wave layout that produced them -> the folded LayerNorm statistics do not depend on the tile choice
 #pragma unroll
-      for (int w = 0; w < WN; ++w) { s += comb[(w * BM + t) * 2]; q += comb[(w * BM + t) * 2 + 1]; }
-      float* so = p.stat_out + ((size_t)(n0 / 64) * M + (m0 + t)) * 2;
-      so[0] = s; so[1] = q;
-      if (BN > 64 && n0 + 64 < N) { so[2 * (size_t)M] = 0.f; so[2 * (size_t)M + 1] = 0.f; }   // 128-wide tiles own two slots
+      for (int gq = 0; gq < BN / 64; ++gq) {
+        if (n0 + gq * 64 >= N) break;
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { s += comb[((size_t)(gq * 4 + f) * BM + t) * 2]; q += comb[((size_t)(gq * 4 + f) * BM + t) * 2 + 1]; }
+        float* so = p.stat_out + ((size_t)(n0 / 64 + gq) * M + (m0 + t)) * 2;
+        so[0] = s; so[1] = q;
+      }
     }
   }
 }
@@ -618,7 +616,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
-  constexpr int lds = NST * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, WN>();
+  constexpr int lds = NST * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
   static bool once = [] {
     return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();

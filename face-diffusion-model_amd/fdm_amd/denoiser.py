@@ -335,9 +335,9 @@ class DenoiserPlan:
             self._gemm("ffn1", ws["h2t"][rb:], wt[pre + "linear1.weight"], Rc, p.ffn, d, bias=w[pre + "linear1.bias"], act=ACT_RELU,
                      out_t=ws["u"][rb:])
             if fuse:           # x2 = h2 + FFN(h2): fp32 + operand copy + per-row partial sums for the folded norm3
-                # (producer of the folded-norm3 partial sums: their rounding order depends on the tile, so not tuned)
-                ops.gemm(ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
-                         out_f32=ws["x2"][rb:], out_t=ws["x2t"][rb:], stat_out=st)
+                # (producer of the folded-norm3 partial sums: written per 64-column group in a tile-independent order)
+                self._gemm("ffn2_stat", ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"],
+                           resid=ws["h2"][rb:], out_f32=ws["x2"][rb:], out_t=ws["x2t"][rb:], stat_out=st)
             else:
                 self._gemm("ffn2", ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
                            out_f32=ws["x1"][rb:])

@@ -96,7 +96,8 @@ typedef struct fdm_gemm_args {
   int kv_L; int kv_Lpad; int kv_hd;
   /* --- LayerNorm folded into the GEMMs around it (bf16 step program; removes the norm3 launch) ---
    * producer: stat_out != NULL -> per-row partial (sum v, sum v^2) of the fp32 outputs of each 64-column
-   *   group are written to stat_out[(n/64) * 2M + 2m + {0,1}] (plain stores, fixed order: deterministic).
+   *   group are written to stat_out[(n/64) * 2M + 2m + {0,1}] (plain stores; summed per 16-column fragment, fragments in
+   *   column order: deterministic AND independent of the output tile, so `tile` never changes results).
    * consumer: ln_stat_in != NULL -> mu_m, rstd_m = f(sum over ln_nparts partials, ln_dim, ln_eps).
    *   ln_colsum != NULL: A holds the RAW (un-normalised) rows and W = W o gamma, so
    *     LN(x) W^T + b  ==  rstd_m (acc - mu_m colsum_n) + bias_n   with bias_n := beta.W_n + b_n;

@@ -240,7 +240,7 @@ def test_gemm_tile_choice_changes_speed_not_results(dtype, monkeypatch):
     plan._tile_cache = {}
     plan._tune_tiles()                 # forced (sampling calls tune lazily, for chains of >= 100 steps)
     assert all(0 <= v <= 4 for v in plan.tiles.values())
-    plan.tiles = {k: 0 for k in ("enc", "qkv", "qkv_ln", "out", "out_ln", "ffn1", "ffn2", "dec", "dec_ln")}
+    plan.tiles = {k: 0 for k in ("enc", "qkv", "qkv_ln", "out", "out_ln", "ffn1", "ffn2", "ffn2_stat", "dec", "dec_ln")}
     base = plan.denoise(inp["x"].to(DEV), t).clone()
     for tile in (TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128):
         plan.tiles = {k: tile for k in plan.tiles}
