@@ -21,10 +21,11 @@
 
 namespace fdm {
 
-// LDS scratch of the LayerNorm-folding epilogue: rowstat[BM][2] (mu, rstd of this block's rows) followed by
-// the cross-wave combine area [WN][BM][2]
-// LayerNorm-folding scratch behind the ring: per-row (mu, rstd) + one (sum, sum of squares) pair per row and 16-column fragment
-template <int BM, int BN> constexpr int gemm_ln_scratch_bytes() { return BM * 2 * (1 + BN / 16) * 4; }
+// LDS scratch of the LayerNorm-folding epilogue behind the ring: rowstat[BM][2] (mu, rstd of this block's rows).  The
+// producer side's per-fragment (sum, sum of squares) pairs [BN / 16][BM][2] live INSIDE the ring (free after the k
+// loop), behind the area of the transposed V tile.
+template <int BM, int BN> constexpr int gemm_ln_scratch_bytes() { return BM * 2 * 4; }
+template <typename T, int BM, int BN> constexpr int gemm_epi_ring_bytes() { return BM * BN * (int)sizeof(T) + BM * 2 * (BN / 16) * 4; }
 
 // Consumer side: mu / rstd of the block's rows from the producer's per-64-column partial sums (fixed order).
 template <int BM>
@@ -126,10 +127,10 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   constexpr int EPC_T = 16 / (int)sizeof(T);
   const bool vt_tile = tile_lds && p.out_vp && n0 >= p.vp_col0 && n0 + BN <= N && (p.kv_L % EPC_T == 0);
   T* tl = (T*)tile_lds;
-  if (vt_tile) __syncthreads();      // every wave is done reading the last ring stage
-  float* comb = rowstat ? rowstat + BM * 2 : nullptr;
+  float* comb = tile_lds ? (float*)(tile_lds + BM * BN * (int)sizeof(T)) : nullptr;
   const bool use_ln = rowstat && p.ln_stat_in;
-  const bool do_stat = rowstat && p.stat_out;
+  const bool do_stat = rowstat && comb && p.stat_out;
+  if (vt_tile || do_stat) __syncthreads();      // every wave is done reading the last ring stage
   // ---- fused epilogue: lane owns C[m = .. + r16][n = .. + 4g + (0..3)] ----
   const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
   const size_t ocol = (size_t)z * p.out_batch_stride;
@@ -496,6 +497,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   static_assert(A_IPW >= 1 && W_IPW >= 1 && MI >= 1 && NI >= 1, "tile too small for the wave grid");
   constexpr int P = A_IPW + W_IPW;
   constexpr int STAGE = (BM + BN) * ROWB;
+  static_assert(NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>(), "epilogue staging does not fit in the ring");
   constexpr bool EARLY_READS = (KCH / 4) * (MI + NI) <= 12;     // fragment registers for a whole k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
@@ -661,6 +663,7 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
     case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);  // 8 waves, 64x32 per wave
     case FDM_TILE_96x128: return gemm_glds_launch_t<T, 96, 128, 2, 2, 4>(a, s);    // 4 waves, 48x64 per wave
+    case FDM_TILE_256x128: return gemm_glds_launch_t<T, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 64x64 per wave, 146 KB LDS
     default: break;
   }
   // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;

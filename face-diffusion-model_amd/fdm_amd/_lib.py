@@ -36,7 +36,7 @@ class GemmArgs(C.Structure):
                 ("sched_fuse", ci), ("sched", SchedArgs)]
 
 
-TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128 = 0, 1, 2, 3, 4
+TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128 = 0, 1, 2, 3, 4, 5
 
 
 class AttnArgs(C.Structure):

@@ -28,7 +28,7 @@ import torch
 
 from . import ops, presets, schedule
 from ._lib import (ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32, TILE_64x64, TILE_96x128, TILE_128x64, TILE_128x128,
-                   FdmError)
+                   TILE_256x128, FdmError)
 
 
 def _dev(t, device):
@@ -253,7 +253,7 @@ class DenoiserPlan:
                     inst = inst + inst
                 base = min(timed(inst, 0), timed(inst, 0))
                 best, best_t = 0, base * 0.97          # switch only for a > 3 % gain over the heuristic
-                for tile in (TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128):
+                for tile in (TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128) + ((TILE_256x128,) if self.Rc >= 1024 else ()):
                     t = min(timed(inst, tile), timed(inst, tile))
                     if t < best_t:
                         best, best_t = tile, t

@@ -126,6 +126,7 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_128x64 2
 #define FDM_TILE_128x128 3
 #define FDM_TILE_96x128 4
+#define FDM_TILE_256x128 5
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -61,7 +61,7 @@ def test_argument_validation_of_the_round1_additions():
     a.kv_hd, a.kv_L = 64, 48                                                                      # M % L
     assert l.fdm_op_gemm(C.byref(a), None) == -2
     a.out_kp = a.out_vp = None
-    a.tile = 9
+    a.tile = 19
     assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"tile" in l.fdm_last_error()
     assert l.fdm_op_vertex_err(16, 16, None, 5, 3, 10, 16, 16, 16, None) == -2                    # region NULL needs R == V
     assert l.fdm_op_motion_std(16, None, None, 10, 3, 10, 16, 16, None) == -1
