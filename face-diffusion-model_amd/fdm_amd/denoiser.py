@@ -281,6 +281,9 @@ class DenoiserPlan:
                 t_h = min(chain_time({}), chain_time({}))
                 t_t = min(chain_time(tuned), chain_time(tuned))
                 self.tiles = tuned if t_t < 0.995 * t_h else {}
+                if os.environ.get("FDM_TUNE_VERBOSE"):
+                    print(f"[fdm tune] rows={self.Rc} candidates={tuned} chain {t_h / 4:.3f} -> {t_t / 4:.3f} ms: "
+                          f"{'kept' if self.tiles else 'rejected'}", flush=True)
         self._tile_cache[key] = dict(self.tiles)
         self._progs = {}                   # programs recorded with the old tiles are rebuilt
 
