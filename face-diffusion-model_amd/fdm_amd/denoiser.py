@@ -398,6 +398,8 @@ class DenoiserPlan:
                 elif kind == "pass" and self.cfg:
                     ops.sched_step(2, x0, None, x0, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0))
         prog.hold(*[v for v in kw.values() if torch.is_tensor(v)])
+        if len(self._progs) >= 8:          # programs are keyed by the pointers they captured (e.g. injected noise): cap the cache
+            self._progs.pop(next(iter(self._progs)))
         self._progs[key] = prog
         return prog
 
