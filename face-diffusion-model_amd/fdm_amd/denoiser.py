@@ -36,6 +36,10 @@ def _dev(t, device):
 
 
 class DenoiserPlan:
+    # Persistent plan state (weights, tables, workspaces, counters) is created with inference mode OFF: callers may wrap
+    # sampling in torch.inference_mode() (the reference decorates its samplers with it) and later call again outside it;
+    # tensors born inside inference mode could not be refilled then.
+    @torch.inference_mode(False)
     def __init__(self, preset, weights, dtype=F32, device="cuda:0"):
         self.p = presets.get(preset)
         self.dtype = dtype
@@ -108,6 +112,7 @@ class DenoiserPlan:
         self._ddim = {}
 
     # ------------------------------------------------------------------------------------------
+    @torch.inference_mode(False)
     def prepare(self, hub, style, emo=None, L=None, cfg=False, chains=None):
         """hub [B, N, 1024] HuBERT features; style [B, n_style]; emo [B, n_emo]; L latent frames.
 
@@ -409,6 +414,7 @@ class DenoiserPlan:
             return self.ws["x0"]
         return self.ws["x0"].view(self.chains, self.rep, self.Mc, self.p.d)[:, 0].reshape(self.M, self.p.d)
 
+    @torch.inference_mode(False)
     def _set_steps(self, ts):
         if len(ts) > self.tseq.numel():
             self.tseq = torch.zeros(len(ts), dtype=torch.int32, device=self.device)

@@ -77,6 +77,7 @@ def _get(w, name):
 
 
 class HubertPlan:
+    @torch.inference_mode(False)      # plan state must stay writable outside a caller's inference_mode block
     def __init__(self, weights, n_layers=None, dtype=F32, device="cuda:0", prefix="", cfg=HUBERT_LARGE):
         self.cfg = cfg
         n_layers = cfg.n_layers if n_layers is None else n_layers

@@ -21,6 +21,7 @@ from .presets import VQ_FFN, VQ_HEADS, VQ_HIDDEN, VQ_LAYERS
 
 
 class VQPlan:
+    @torch.inference_mode(False)      # plan state must stay writable outside a caller's inference_mode block
     def __init__(self, preset, weights, dtype=F32, device="cuda:0"):
         self.p = presets.get(preset)
         self.dtype, self.td = dtype, ops.tdtype(dtype)

@@ -159,3 +159,21 @@ def test_bf16_module_surface_tracks_fp32(monkeypatch):
         res[name] = (out.cpu(), latent.cpu())
     assert res["fp32"][0].shape == (1, 74, 15069)
     assert mad(res["fp32"][1], res["bf16"][1]) < 0.15          # latents O(4)
+
+
+def test_plans_survive_callers_inference_mode_blocks():
+    """The reference decorates its samplers with @torch.inference_mode(); a plan first used inside such a block must keep
+    working outside it (its workspaces and counters are refilled in place on every call)."""
+    from fdm_amd.denoiser import DenoiserPlan
+    from fdm_amd._lib import F32
+    from oracle import weights as W
+    inp = W.synth_inputs("vocaset_tiny", 2, 16, seed=5)
+    with torch.inference_mode():
+        plan = DenoiserPlan("vocaset_tiny", W.make_fdm_weights("vocaset_tiny"), F32, "cuda:0")
+        plan.prepare(inp["hub"], inp["style"], L=16)
+        a = plan.sample_ddpm(inp["x"].to("cuda:0"), [5, 4, 3, 2, 1, 0], seed=3).clone()
+    b = plan.sample_ddpm(inp["x"].to("cuda:0"), [5, 4, 3, 2, 1, 0], seed=3)
+    plan.prepare(inp["hub"][:1], inp["style"][:1], L=16)
+    with torch.inference_mode():
+        c = plan.sample_ddpm(inp["x"][:1].to("cuda:0"), [5, 4, 3, 2, 1, 0], seed=3)
+    assert torch.equal(a, b) and torch.equal(c[0], a[0])
