@@ -170,7 +170,7 @@ def main():
         plan.prepare(hub_plan.forward(wav), inp["style"][sl], None, L=L)
     plan._tune_tiles()
 
-    def one_call():
+    def one_call(collect=True):
         if e2e:      # HuBERT once per clip + per-clip tables + T-step chain + quant + decode to vertices
             plan.prepare(hub_plan.forward(wav), inp["style"][sl], None, L=L)
         if sampler == "ddpm":
@@ -179,7 +179,7 @@ def main():
             out = plan.sample_ddim(xT, T)
         if e2e:
             out = vq_plan.decode(vq_plan.quant(out * (1.5 / 1024))[0])
-        return gather_clips(out, dist)
+        return gather_clips(out, dist) if collect else out
 
     def fence():
         if dist is not None:
@@ -190,7 +190,7 @@ def main():
     # binary reads 2 % lower when the timed region starts within ~1 s of the first GPU load than after ~3 s of load.
     t_spin = time.perf_counter()
     while a.warmup > 0 and time.perf_counter() - t_spin < 3.0:
-        one_call()
+        one_call(collect=False)        # rank-local only: a time-bounded loop must not contain a collective
         torch.cuda.synchronize()
     for _ in range(a.warmup):
         one_call()
