@@ -179,7 +179,7 @@ def main():
             out = plan.sample_ddim(xT, T)
         if e2e:
             out = vq_plan.decode(vq_plan.quant(out * (1.5 / 1024))[0])
-        return gather_clips(out, dist) if collect else out
+        return gather_clips(out, dist, sizes=[B] * world) if collect else out     # equal shards: no size exchange
 
     def fence():
         if dist is not None:
