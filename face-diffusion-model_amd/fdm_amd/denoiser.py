@@ -289,6 +289,9 @@ class DenoiserPlan:
                 if os.environ.get("FDM_TUNE_VERBOSE"):
                     print(f"[fdm tune] rows={self.Rc} candidates={tuned} chain {t_h / 4:.3f} -> {t_t / 4:.3f} ms: "
                           f"{'kept' if self.tiles else 'rejected'}", flush=True)
+        ov = os.environ.get("FDM_TILE_OVERRIDE")      # experiments: "qkv_ln=5,ffn1=3" forces call sites after the tuning
+        if ov:
+            self.tiles = dict(self.tiles, **{k: int(v) for k, v in (kv.split("=") for kv in ov.split(","))})
         self._tile_cache[key] = dict(self.tiles)
         self._progs = {}                   # programs recorded with the old tiles are rebuilt
 
