@@ -28,7 +28,7 @@ import torch
 
 from . import ops, presets, schedule
 from ._lib import (ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32, TILE_64x64, TILE_96x128, TILE_128x64, TILE_128x128,
-                   TILE_256x128, FdmError)
+                   TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, FdmError)
 
 
 def _dev(t, device):
@@ -252,17 +252,19 @@ class DenoiserPlan:
                 e1.synchronize()
                 return e0.elapsed_time(e1)
 
+            runner_up = {}
             for label, inst in calls.items():
                 inst = [(a, {k: v for k, v in kw.items() if k != "incr_counter"}) for a, kw in inst]
                 while len(inst) < 4:
                     inst = inst + inst
                 base = min(timed(inst, 0), timed(inst, 0))
-                best, best_t = 0, base * 0.97          # switch only for a > 3 % gain over the heuristic
-                for tile in (TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128) + ((TILE_256x128,) if self.Rc >= 1024 else ()):
-                    t = min(timed(inst, tile), timed(inst, tile))
-                    if t < best_t:
-                        best, best_t = tile, t
-                self.tiles[label] = best
+                cand = [(base * 0.97, 0)]               # switch only for a > 3 % gain over the heuristic
+                for tile in (TILE_64x64, TILE_64x64_S3, TILE_128x64, TILE_128x64_S3, TILE_128x128, TILE_96x128) + ((TILE_256x128,) if self.Rc >= 1024 else ()):
+                    cand.append((min(timed(inst, tile), timed(inst, tile)), tile))
+                cand.sort()
+                self.tiles[label] = cand[0][1]
+                if len(cand) > 1 and cand[1][0] < cand[0][0] * 1.05:
+                    runner_up[label] = cand[1][1]       # too close to call in isolation: settled inside the chain below
             # the isolated timings can mislead (cache state inside the step differs): keep the tuned set only if one
             # whole denoiser pass of a clip group is faster with it than with the heuristic
             tuned = dict(self.tiles)
@@ -282,9 +284,14 @@ class DenoiserPlan:
                 e1.synchronize()
                 return e0.elapsed_time(e1)
 
-            if any(tuned.values()):
+            if any(tuned.values()) or runner_up:
                 t_h = min(chain_time({}), chain_time({}))
                 t_t = min(chain_time(tuned), chain_time(tuned))
+                for label, alt in runner_up.items():      # close calls: try the runner-up in place, keep what the chain prefers
+                    trial = dict(tuned, **{label: alt})
+                    t_a = min(chain_time(trial), chain_time(trial))
+                    if t_a < 0.997 * t_t:
+                        tuned, t_t = trial, t_a
                 self.tiles = tuned if t_t < 0.995 * t_h else {}
                 if os.environ.get("FDM_TUNE_VERBOSE"):
                     print(f"[fdm tune] rows={self.Rc} candidates={tuned} chain {t_h / 4:.3f} -> {t_t / 4:.3f} ms: "
