@@ -667,6 +667,7 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);   // 3-stage ring: 48 KB -> 3 workgroups per CU
     case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
     case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 32 KB -> 4 workgroups per CU
+    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);    // 4 waves, 16x32 per wave, 36 KB
     default: break;
   }
   // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;

@@ -36,7 +36,7 @@ class GemmArgs(C.Structure):
                 ("sched_fuse", ci), ("sched", SchedArgs)]
 
 
-TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2 = 0, 1, 2, 3, 4, 5, 6, 7, 8
+TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 class AttnArgs(C.Structure):

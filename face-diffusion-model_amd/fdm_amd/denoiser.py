@@ -28,7 +28,8 @@ import torch
 
 from . import ops, presets, schedule
 from ._lib import (ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32, TILE_64x64, TILE_96x128, TILE_128x64, TILE_128x128,
-                   TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, FdmError)
+                   TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3,
+                   FdmError)
 
 
 def _dev(t, device):
@@ -259,7 +260,7 @@ class DenoiserPlan:
                     inst = inst + inst
                 base = min(timed(inst, 0), timed(inst, 0))
                 cand = [(base * 0.97, 0)]               # switch only for a > 3 % gain over the heuristic
-                for tile in (TILE_64x64, TILE_64x64_S3, TILE_64x64_S2, TILE_128x64, TILE_128x64_S3, TILE_128x128, TILE_96x128) + ((TILE_256x128,) if self.Rc >= 1024 else ()):
+                for tile in (TILE_64x64, TILE_64x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_128x64, TILE_128x64_S3, TILE_128x128, TILE_96x128) + ((TILE_256x128,) if self.Rc >= 1024 else ()):
                     cand.append((min(timed(inst, tile), timed(inst, tile)), tile))
                 cand.sort()
                 self.tiles[label] = cand[0][1]

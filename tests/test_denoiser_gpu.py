@@ -232,17 +232,17 @@ def test_full_size_cfg2_chain_properties():
 def test_gemm_tile_choice_changes_speed_not_results(dtype, monkeypatch):
     """Plan-time tile tuning (DenoiserPlan._tune_tiles): every output tile accumulates k in the same order, so forcing
     any tile at every tuned call site gives bit-identical latents; FDM_TUNE=0 (library heuristic) likewise."""
-    from fdm_amd._lib import TILE_64x64, TILE_64x64_S3, TILE_128x64_S3, TILE_96x128, TILE_128x64, TILE_128x128, TILE_256x128
+    from fdm_amd._lib import TILE_64x64, TILE_64x64_S3, TILE_128x64_S3, TILE_96x128, TILE_64x64_S2, TILE_32x64_S3, TILE_128x64, TILE_128x128, TILE_256x128
     L, t = 70, 432
     inp = W.synth_inputs("vocaset", 2, L, seed=5)
     plan, _ = plan_for("vocaset", dtype)
     plan.prepare(inp["hub"], inp["style"], L=L)
     plan._tile_cache = {}
     plan._tune_tiles()                 # forced (sampling calls tune lazily, for chains of >= 100 steps)
-    assert all(0 <= v <= 4 for v in plan.tiles.values())
+    assert all(0 <= v <= 9 for v in plan.tiles.values())
     plan.tiles = {k: 0 for k in ("enc", "qkv", "qkv_ln", "out", "out_ln", "ffn1", "ffn2", "ffn2_stat", "dec", "dec_ln")}
     base = plan.denoise(inp["x"].to(DEV), t).clone()
-    for tile in (TILE_64x64, TILE_64x64_S3, TILE_128x64, TILE_128x64_S3, TILE_128x128, TILE_96x128, TILE_256x128):
+    for tile in (TILE_64x64, TILE_64x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_128x64, TILE_128x64_S3, TILE_128x128, TILE_96x128, TILE_256x128):
         plan.tiles = {k: tile for k in plan.tiles}
         plan._progs = {}
         assert torch.equal(plan.denoise(inp["x"].to(DEV), t), base), f"tile {tile}"
