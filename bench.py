@@ -168,7 +168,7 @@ def main():
     # plan-time work, outside the timed region: GEMM tile tuning for this shape (cached in the plan; ~0.1 s)
     if e2e:
         plan.prepare(hub_plan.forward(wav), inp["style"][sl], None, L=L)
-    plan._tune_tiles()
+    plan.tune()
 
     def one_call(collect=True):
         if e2e:      # HuBERT once per clip + per-clip tables + T-step chain + quant + decode to vertices

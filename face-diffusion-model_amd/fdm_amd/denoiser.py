@@ -50,7 +50,7 @@ class DenoiserPlan:
         if p.head_dim not in (64, 128, 256):
             raise FdmError(f"denoiser head_dim {p.head_dim} unsupported (64, 128, 256)")
         self.stream = torch.cuda.Stream(device=dv)
-        self.tiles, self._tune_rec, self._tile_cache = {}, None, {}
+        self.tiles, self._tune_rec, self._tile_cache, self._steps_seen = {}, None, {}, {}
         w = {k: _dev(v, dv) for k, v in weights.items() if not k.startswith("audio_encoder.") and k != "PE.pe"}
         self.w32 = w
         need = ["audio_extract.0.weight", "audio_extract.2.weight", "time_embedd.0.weight", "style_embedd.weight",
@@ -224,16 +224,29 @@ class DenoiserPlan:
             self._tune_rec.setdefault(label, []).append((a, dict(kw)))
         ops.gemm(*a, tile=self.tiles.get(label, 0), **kw)
 
+    def tune(self):
+        """Tune the GEMM tiles for the prepared shape now (plan-time work; sampling calls otherwise do it lazily)."""
+        self._tune_tiles()
+
     def _tune_tiles(self, n_steps=None):
         """Time the candidate output tiles of every GEMM call site of the step at this plan's shapes and keep the
         fastest.  Each candidate runs the call site's 8 per-layer instances (distinct weights, so they come from
         beyond L2 as they do inside the step) as a replayed graph; ~50 ms in all, cached per shape, and only done for
-        chains long enough to repay it (n_steps >= 100, or n_steps=None to force).  Every tile accumulates k in the
+        shapes the plan keeps being used at (after 2000 steps at the shape; n_steps=None forces, as bench.py does).  Every tile accumulates k in the
         same order, so the choice changes speed only, never results.  FDM_TUNE=0 keeps the library heuristic."""
         key = (self.Rc, self.Mc, self.L, self.rep)
-        if os.environ.get("FDM_TUNE", "1") == "0" or key in self._tile_cache or (n_steps is not None and n_steps < 100):
+        if os.environ.get("FDM_TUNE", "1") == "0" or key in self._tile_cache:
             return
+        if n_steps is not None:
+            # lazy: the ~0.2 s of tuning repays itself after a few thousand diffusion steps, so a plan tunes a shape only
+            # once it has already run 2000 steps at it (repeated / served use); one-shot calls never pay.  n_steps=None forces.
+            seen = self._steps_seen.get(key, 0)
+            self._steps_seen[key] = seen + n_steps
+            if seen < 2000:
+                return
         self.tiles, self._tune_rec = {}, {}
+        import time as _time
+        _t0 = _time.perf_counter()
         with torch.cuda.stream(self.stream):
             with ops.Program():            # dry recording of one chain: captures each call site's arguments, runs nothing
                 self._record_chain(0)
@@ -296,7 +309,7 @@ class DenoiserPlan:
                 self.tiles = tuned if t_t < 0.995 * t_h else {}
                 if os.environ.get("FDM_TUNE_VERBOSE"):
                     print(f"[fdm tune] rows={self.Rc} candidates={tuned} chain {t_h / 4:.3f} -> {t_t / 4:.3f} ms: "
-                          f"{'kept' if self.tiles else 'rejected'}", flush=True)
+                          f"{'kept' if self.tiles else 'rejected'} ({_time.perf_counter() - _t0:.2f} s)", flush=True)
         ov = os.environ.get("FDM_TILE_OVERRIDE")      # experiments: "qkv_ln=5,ffn1=3" forces call sites after the tuning
         if ov:
             self.tiles = dict(self.tiles, **{k: int(v) for k, v in (kv.split("=") for kv in ov.split(","))})

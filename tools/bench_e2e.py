@@ -32,6 +32,7 @@ sty = torch.eye(8)[torch.arange(B) % 8]
 _, t_p = timed('prepare (AF, C1 tables)', lambda: den.prepare(hub, sty, L=L))
 xT = torch.randn(B, L * 16, 64, device=DEV)
 ts = list(range(T - 1, -1, -1))
+den.tune()
 den.sample_ddpm(xT, ts[:5], seed=1)
 lat, t_s = timed(f'sample {T} DDPM steps', lambda: den.sample_ddpm(xT, ts, seed=1))
 lat = lat * (1.5 / 256 / 4)

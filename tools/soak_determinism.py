@@ -13,6 +13,7 @@ for preset, B, L, T, cfg, dt, reps in (("vocaset", 4, 200, 1000, False, BF16, 6)
     plan = DenoiserPlan(preset, W.make_fdm_weights(preset), dt, DEV)
     hub = inp["hub"][:, :, :768].contiguous() if preset == "biwi" else inp["hub"]
     plan.prepare(hub, inp["style"], inp.get("emo"), L=L, cfg=cfg)
+    plan.tune()
     x = inp["x"].to(DEV)
     ts = list(range(999, 999 - T, -1))
     ref = None
