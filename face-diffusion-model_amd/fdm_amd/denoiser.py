@@ -271,10 +271,10 @@ class DenoiserPlan:
                 inst = [(a, {k: v for k, v in kw.items() if k != "incr_counter"}) for a, kw in inst]
                 while len(inst) < 4:
                     inst = inst + inst
-                base = min(timed(inst, 0), timed(inst, 0))
+                base = min(timed(inst, 0), timed(inst, 0), timed(inst, 0))
                 cand = [(base * 0.97, 0)]               # switch only for a > 3 % gain over the heuristic
                 for tile in (TILE_64x64, TILE_64x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_128x64, TILE_128x64_S3, TILE_128x128, TILE_96x128) + ((TILE_256x128,) if self.Rc >= 1024 else ()):
-                    cand.append((min(timed(inst, tile), timed(inst, tile)), tile))
+                    cand.append((min(timed(inst, tile), timed(inst, tile), timed(inst, tile)), tile))
                 cand.sort()
                 self.tiles[label] = cand[0][1]
                 if len(cand) > 1 and cand[1][0] < cand[0][0] * 1.05:
