@@ -35,7 +35,7 @@ template <typename T> __device__ __forceinline__ float fexp(float x) {
   else return __builtin_amdgcn_exp2f(x);
 }
 
-template <typename T, int HD, int QS, int DBG = 0>
+template <typename T, int HD, int QS>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
   // QS = 16-query sub-tiles per workgroup (1 or 2).  With QS = 2 every K / V^T fragment fetched from L2 feeds
   // two S^T and two O^T products: the kernel is bound by L2 -> register fragment traffic, which this halves.
@@ -103,15 +103,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
     for (int s = 0; s < NSUB; ++s)
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        if (DBG == 2) kcur[s][ks] = u32x4{(unsigned)kt, 1u, 2u, (unsigned)lane};
-        else kcur[s][ks] = *(const u32x4*)(Kp + (size_t)((kt * NSUB + s) * NKS + ks) * (64 * EPC));
+        kcur[s][ks] = *(const u32x4*)(Kp + (size_t)((kt * NSUB + s) * NKS + ks) * (64 * EPC));
       }
     u32x4 vf[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      if (DBG == 2) vf[c] = u32x4{(unsigned)kt, 1u, 2u, (unsigned)lane};
-      else vf[c] = *(const u32x4*)(Vp + (size_t)(kt * NC + c) * (64 * EPC));
-    }
+    for (int c = 0; c < NC; ++c) vf[c] = *(const u32x4*)(Vp + (size_t)(kt * NC + c) * (64 * EPC));
 #pragma unroll
     for (int u = 0; u < QS; ++u) {
       // a causal sub-tile whose last query precedes this key tile sees none of it (wave-uniform skip);
@@ -227,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
     for (int w = 0; w < 4; ++w) { sw[w] = fexp<T>(mw[w] - ms); lsum += sw[w] * part_l[w][q]; }   // exp(-inf) = 0 for idle waves
     const float inv = 1.f / lsum;
     if (qq < L) {
-      T* op = (T*)p.O + ((size_t)b * L + qq) * p.ldo + (size_t)h * HD + e0;
+      const size_t oo = ((size_t)b * L + qq) * p.ldo + (size_t)h * HD + e0;
 #pragma unroll
       for (int j = 0; j < EPT; j += 4) {
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -235,11 +231,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
         for (int w = 0; w < 4; ++w) v += *(const f32x4*)&part_o[w][q][e0 + j] * sw[w];
         v *= inv;
         if constexpr (sizeof(T) == 4) {
-          *(f32x4*)(op + j) = v;
+          // fp32 attention feeding a split-operand GEMM (F16X3 / BF16X3 step programs): O is written as the plane pair
+          if (p.o_split == FDM_F16X3) store_opnd4<f16x3_t>((f16*)p.O + oo + j, p.o_lo_off, v);
+          else if (p.o_split == FDM_BF16X3) store_opnd4<bf16x3_t>((bf16*)p.O + oo + j, p.o_lo_off, v);
+          else *(f32x4*)((float*)p.O + oo + j) = v;
         } else {
-          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-          bf16x4 ob = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *(bf16x4*)(op + j) = ob;
+          store_opnd4<T>((T*)p.O + oo + j, 0, v);
         }
       }
     }
@@ -250,14 +247,8 @@ template <typename T, int HD>
 static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   // two query sub-tiles per workgroup once the sequence is long enough that halving the K / V traffic matters more
   // than the number of workgroups; head_dim 256 keeps one (register budget)
-  static const int dbg = getenv("FDM_ATTN_DBG") ? atoi(getenv("FDM_ATTN_DBG")) : 0;
   static const int qs2 = getenv("FDM_ATTN_QS2") ? atoi(getenv("FDM_ATTN_QS2")) : 384;
   const int groups = (a.B * a.H + 7) / 8 * 8;        // (clip, head) pairs padded to whole XCD rounds
-  if (HD == 128 && sizeof(T) == 2 && dbg) {
-    dim3 grid((a.L + 15) / 16 * groups);
-    hipLaunchKernelGGL((attn_kernel<T, HD, 1, (HD == 128 && sizeof(T) == 2) ? 2 : 0>), grid, dim3(256), 0, s, a);
-    return;
-  }
   if (HD <= 128 && a.L >= qs2) {
     dim3 grid((a.L + 31) / 32 * groups);
     hipLaunchKernelGGL((attn_kernel<T, HD, (HD <= 128 ? 2 : 1)>), grid, dim3(256), 0, s, a);
@@ -267,16 +258,11 @@ static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   }
 }
 
-static hipError_t attn_launch(const fdm_attn_args& a, hipStream_t s) {
-  if (a.dtype == FDM_BF16) {
-    if (a.hd == 256) attn_launch_t<bf16, 256>(a, s);
-    else if (a.hd == 128) attn_launch_t<bf16, 128>(a, s);
-    else attn_launch_t<bf16, 64>(a, s);
-  } else {
-    if (a.hd == 256) attn_launch_t<float, 256>(a, s);
-    else if (a.hd == 128) attn_launch_t<float, 128>(a, s);
-    else attn_launch_t<float, 64>(a, s);
-  }
+template <typename T>
+static hipError_t attn_launch_dtype(const fdm_attn_args& a, hipStream_t s) {
+  if (a.hd == 256) attn_launch_t<T, 256>(a, s);
+  else if (a.hd == 128) attn_launch_t<T, 128>(a, s);
+  else attn_launch_t<T, 64>(a, s);
   return hipGetLastError();
 }
 

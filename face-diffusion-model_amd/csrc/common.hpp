@@ -9,8 +9,10 @@
 namespace fdm {
 
 typedef __bf16 bf16;
+typedef _Float16 f16;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 
@@ -35,6 +37,65 @@ template <> struct Mma<float> {
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
   }
 };
+
+// One k-step of a 16-bit fragment pair whose element type is E (bf16 or fp16): same lane map for both.
+template <typename E> __device__ __forceinline__ void mma16(f32x4& acc, const u32x4& a, const u32x4& b) {
+  if constexpr (std::is_same<E, f16>::value)
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  else
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Operand kinds.  Besides plain fp32 and bf16 matrices the GEMMs take SPLIT operands: x = hi + lo / SCALE with hi, lo
+// stored as two planes of a 16-bit type (plane 1 starts `lo_off` elements after plane 0), and the product evaluated as
+// hi.hi + (hi.lo + lo.hi) / SCALE on the 16-bit MFMA (three passes; the lo.lo term is below the representation error).
+//   f16x3_t : fp16 planes, 11 significant bits each -> 22 bits per operand, fp32-class results (SCALE = 2^11 keeps the
+//             residual plane in fp16's normal range; the two small products are summed in their own accumulator)
+//   bf16x3_t: bf16 planes, 8 bits each -> 16 bits per operand (kept for comparison: ~5e-5 per denoiser call)
+// E = element type in memory, NP = planes, KV = element type of the packed K / V outputs of a QKV projection in that
+// mode (split modes feed the fp32 attention kernel).
+// ---------------------------------------------------------------------------------------------------
+struct f16x3_t {};
+struct bf16x3_t {};
+template <typename T> struct Opnd { using E = T; using KV = T; static constexpr int NP = 1; static constexpr float SCALE = 1.f; };
+template <> struct Opnd<f16x3_t> { using E = f16; using KV = float; static constexpr int NP = 2; static constexpr float SCALE = 2048.f; };
+template <> struct Opnd<bf16x3_t> { using E = bf16; using KV = float; static constexpr int NP = 2; static constexpr float SCALE = 1.f; };
+
+// Store 4 consecutive fp32 values v as operand kind T at dst (split kinds: hi plane at dst, lo plane at dst + lo_off).
+template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, long long lo_off, const f32x4& v) {
+  using E = typename Opnd<T>::E;
+  if constexpr (std::is_same<T, float>::value) {
+    *(f32x4*)dst = v;
+  } else if constexpr (Opnd<T>::NP == 1) {
+    typedef __attribute__((ext_vector_type(4))) E e4;
+    e4 o = {(E)v[0], (E)v[1], (E)v[2], (E)v[3]};
+    *(e4*)dst = o;
+  } else {
+    typedef __attribute__((ext_vector_type(4))) E e4;
+    e4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // fp16 overflows at 65504: clamp (activations / weights on this path are O(1..100); a clamp keeps a stray value finite)
+      const float x = std::is_same<E, f16>::value ? fminf(fmaxf(v[j], -65504.f), 65504.f) : v[j];
+      h[j] = (E)x;
+      l[j] = (E)((x - (float)h[j]) * Opnd<T>::SCALE);
+    }
+    *(e4*)dst = h;
+    *(e4*)((E*)dst + lo_off) = l;
+  }
+}
+template <typename T> __device__ __forceinline__ void store_opnd1(void* dst, long long lo_off, float v) {
+  using E = typename Opnd<T>::E;
+  if constexpr (Opnd<T>::NP == 1) {
+    *(E*)dst = (E)v;
+  } else {
+    const float x = std::is_same<E, f16>::value ? fminf(fmaxf(v, -65504.f), 65504.f) : v;
+    const E h = (E)x;
+    *(E*)dst = h;
+    *((E*)dst + lo_off) = (E)((x - (float)h) * Opnd<T>::SCALE);
+  }
+}
 
 __device__ __forceinline__ float to_f32(float v) { return v; }
 __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }

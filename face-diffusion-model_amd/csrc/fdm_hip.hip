@@ -11,9 +11,8 @@
 #include <vector>
 
 #include "../../include/fdm_hip.h"
-#include "attention.hpp"
 #include "elementwise.hpp"
-#include "gemm.hpp"
+#include "kernels.hpp"
 
 namespace {
 
@@ -93,8 +92,13 @@ static bool gemm_act_heavy_host(int act) { return act == FDM_ACT_MISH || act == 
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W) return fail(FDM_ERR_ARG, "gemm: null operand");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return fail(FDM_ERR_SHAPE, "gemm: M,N,K must be positive (%d,%d,%d)", a->M, a->N, a->K);
-  if (a->dtype != FDM_F32 && a->dtype != FDM_BF16) return fail(FDM_ERR_ARG, "gemm: bad dtype %d", a->dtype);
-  const int bk = a->dtype == FDM_BF16 ? 64 : 32, epc = a->dtype == FDM_BF16 ? 8 : 4;
+  if (a->dtype < FDM_F32 || a->dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "gemm: bad dtype %d", a->dtype);
+  const bool split = a->dtype == FDM_F16X3 || a->dtype == FDM_BF16X3;
+  const int bk = a->dtype == FDM_F32 ? 32 : 64, epc = a->dtype == FDM_F32 ? 4 : 8;
+  if (split && (a->a_lo_off <= 0 || a->w_lo_off <= 0 || a->a_lo_off % epc || a->w_lo_off % epc))
+    return fail(FDM_ERR_ARG, "gemm: split operands need positive a_lo_off / w_lo_off (multiples of 8 elements)");
+  if (split && a->out_t && a->out_t_lo_off <= 0) return fail(FDM_ERR_ARG, "gemm: split out_t needs out_t_lo_off");
+  if (split && (a->stat_out || a->ln_stat_in)) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding is a bf16-mode feature");
   if (a->K % bk) return fail(FDM_ERR_SHAPE, "gemm: K=%d not a multiple of %d", a->K, bk);
   if (a->lda % epc || a->ldw % epc || !aligned16(a->A) || !aligned16(a->W)) return fail(FDM_ERR_ARG, "gemm: operands need 16-byte aligned rows");
   if (a->a_batch_stride % epc || a->w_batch_stride % epc) return fail(FDM_ERR_ARG, "gemm: batch strides need 16-byte alignment");
@@ -134,6 +138,9 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream) {
   if (a->hd != 64 && a->hd != 128 && a->hd != 256) return fail(FDM_ERR_SHAPE, "attention: head_dim %d unsupported (64, 128, 256)", a->hd);
   if (a->B <= 0 || a->H <= 0 || a->L <= 0) return fail(FDM_ERR_SHAPE, "attention: B,H,L must be positive");
   if (a->Lpad < a->L || a->Lpad % 32) return fail(FDM_ERR_SHAPE, "attention: Lpad=%d must be a multiple of 32 >= L", a->Lpad);
+  if (a->dtype != FDM_F32 && a->dtype != FDM_BF16) return fail(FDM_ERR_ARG, "attention: bad dtype %d (split modes run the fp32 kernel with o_split)", a->dtype);
+  if (a->o_split && (a->dtype != FDM_F32 || (a->o_split != FDM_F16X3 && a->o_split != FDM_BF16X3) || a->o_lo_off <= 0))
+    return fail(FDM_ERR_ARG, "attention: o_split needs dtype FDM_F32, a split kind and o_lo_off");
   const int epc = a->dtype == FDM_BF16 ? 8 : 4;
   if (a->ldq % epc || a->ldo % 4 || !aligned16(a->Q) || !aligned16(a->Kp) || !aligned16(a->Vp) || !aligned16(a->O))
     return fail(FDM_ERR_ARG, "attention: operands need 16-byte aligned rows");
@@ -148,8 +155,8 @@ int fdm_op_pack_kv(const void* K, long long ldk, const void* V, long long ldv, v
   if (B <= 0 || H <= 0 || L <= 0 || Lpad < L || Lpad % 32 || hd <= 0 || hd % 16) return fail(FDM_ERR_SHAPE, "pack_kv: bad geometry");
   if (dtype != FDM_F32 && dtype != FDM_BF16) return fail(FDM_ERR_ARG, "pack_kv: bad dtype %d", dtype);
   return submit([=](hipStream_t s) {
-    return dtype == FDM_BF16 ? fdm::pack_kv_launch<fdm::bf16>(K, ldk, V, ldv, Kp, Vp, B, H, L, Lpad, hd, s)
-                             : fdm::pack_kv_launch<float>(K, ldk, V, ldv, Kp, Vp, B, H, L, Lpad, hd, s);
+    return dtype == FDM_BF16 ? fdm::pack_kv_launch_bf16(K, ldk, V, ldv, Kp, Vp, B, H, L, Lpad, hd, s)
+                             : fdm::pack_kv_launch_f32(K, ldk, V, ldv, Kp, Vp, B, H, L, Lpad, hd, s);
   }, stream, "pack_kv");
 }
 
@@ -158,9 +165,16 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
   if (a->d != 256 && a->d != 512 && a->d != 768 && a->d != 1024) return fail(FDM_ERR_SHAPE, "layernorm: d=%d unsupported (256, 512, 768, 1024)", a->d);
   if (a->M <= 0) return fail(FDM_ERR_SHAPE, "layernorm: M must be positive");
   if (!a->y_f32 && !a->y_t) return fail(FDM_ERR_ARG, "layernorm: no output");
+  if (a->dtype < FDM_F32 || a->dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "layernorm: bad dtype %d", a->dtype);
+  if (a->y_t && a->dtype >= FDM_F16X3 && (a->y_t_lo_off <= 0 || a->y_t_lo_off % 4)) return fail(FDM_ERR_ARG, "layernorm: split y_t needs y_t_lo_off");
   fdm_ln_args c = *a;
   return submit([c](hipStream_t s) {
-    return c.dtype == FDM_BF16 ? fdm::ln_launch_t<fdm::bf16>(c, s) : fdm::ln_launch_t<float>(c, s);
+    switch (c.dtype) {
+      case FDM_BF16: return fdm::ln_launch_t<fdm::bf16>(c, s);
+      case FDM_F16X3: return fdm::ln_launch_t<fdm::f16x3_t>(c, s);
+      case FDM_BF16X3: return fdm::ln_launch_t<fdm::bf16x3_t>(c, s);
+      default: return fdm::ln_launch_t<float>(c, s);
+    }
   }, stream, "layernorm");
 }
 
@@ -171,15 +185,20 @@ int fdm_op_sched_step(const fdm_sched_args* a, void* stream) {
   if (a->mode == 1 && (!a->x || !a->sra || !a->srm1 || !a->sqrt_an || !a->c_n)) return fail(FDM_ERR_ARG, "sched: DDIM tables missing");
   if (a->mode < 0 || a->mode > 2) return fail(FDM_ERR_ARG, "sched: bad mode %d", a->mode);
   if (a->mode == 0 && !a->noise && (a->n_per_clip <= 0 || a->n_per_clip % 4)) return fail(FDM_ERR_SHAPE, "sched: n_per_clip must be a positive multiple of 4");
+  if (a->x_out_t && a->out_dtype >= FDM_F16X3 && (a->x_out_t_lo_off <= 0 || a->x_out_t_lo_off % 4)) return fail(FDM_ERR_ARG, "sched: split x_out_t needs x_out_t_lo_off");
   fdm_sched_args c = *a;
   return submit([c](hipStream_t s) { return fdm::sched_launch(c, s); }, stream, "sched");
 }
 
 int fdm_op_cast(const float* src, void* dst, long long n, int dtype, void* stream) {
   if (!src || !dst || n <= 0) return fail(FDM_ERR_ARG, "cast: bad argument");
+  if (dtype < FDM_F32 || dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "cast: bad dtype %d", dtype);
   return submit([=](hipStream_t s) {
-    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::cast_kernel<fdm::bf16>), dim3(grid_for(n)), dim3(256), 0, s, src, (fdm::bf16*)dst, n);
-    else hipLaunchKernelGGL((fdm::cast_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, src, (float*)dst, n);
+    const dim3 g(grid_for(n)), b(256);
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::cast_kernel<fdm::bf16>), g, b, 0, s, src, (fdm::bf16*)dst, n);
+    else if (dtype == FDM_F16X3) hipLaunchKernelGGL((fdm::cast_kernel<fdm::f16x3_t>), g, b, 0, s, src, (fdm::f16*)dst, n);
+    else if (dtype == FDM_BF16X3) hipLaunchKernelGGL((fdm::cast_kernel<fdm::bf16x3_t>), g, b, 0, s, src, (fdm::bf16*)dst, n);
+    else hipLaunchKernelGGL((fdm::cast_kernel<float>), g, b, 0, s, src, (float*)dst, n);
     return hipGetLastError();
   }, stream, "cast");
 }

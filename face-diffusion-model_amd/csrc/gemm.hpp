@@ -2,21 +2,23 @@
 //
 // Layout / tiling
 //  * A and W are both K-contiguous ("NT" GEMM: nn.Linear weights are [out, in]).
-//  * Workgroup = 256 threads = 4 wavefronts (2 x 2), tile BM x BN, k-tile = 128 bytes of K per
-//    row (64 bf16 / 32 fp32), so the LDS image and the staging code are byte-identical for both
-//    operand types.  LDS rows are 128 B with a 16-byte-chunk XOR swizzle (chunk ^ (row & 7)) so
-//    that the ds_read_b128 fragment reads of 16 different rows at one k-chunk spread over 8 slots.
-//  * HBM/L2 -> VGPR (global_load_dwordx4) -> LDS (ds_write_b128), double-buffered: the loads of
-//    k-tile t+1 are issued before the MFMAs of k-tile t and written to the other LDS buffer after
-//    them; one barrier per k-tile.
+//  * Workgroup = WM x WN wavefronts, tile BM x BN, k-tile = 128 bytes of K per row (64 16-bit / 32 fp32
+//    elements), so the LDS image and the staging code are byte-identical for every operand kind.  LDS rows
+//    are 128 B with a 16-byte-chunk XOR swizzle (chunk ^ (row & 7)) so that the ds_read_b128 fragment reads
+//    of 16 different rows at one k-chunk spread over 8 slots.
+//  * Operand kinds (common.hpp, Opnd<T>): fp32 (exact, v_mfma_f32_16x16x4_f32), bf16 (v_mfma_f32_16x16x32_bf16),
+//    and the split kinds f16x3 / bf16x3: hi and lo planes of both operands ride the same ring (a stage holds
+//    A_hi, A_lo, W_hi, W_lo) and every fragment pair takes three 16-bit MFMAs (hi.hi into the main accumulator,
+//    hi.lo + lo.hi into a second one that is scaled by 1 / SCALE once, after the k loop).
 //  * Operands are swapped into the MFMA (W rows feed the A port, activation rows the B port), so a
 //    lane ends up with 4 consecutive output columns n of one row m: the epilogue then reads
-//    bias/residual and writes outputs with 16-byte (fp32) / 8-byte (bf16) vector accesses.
+//    bias/residual and writes outputs with 16-byte (fp32) / 8-byte (16-bit) vector accesses.
 //  * Epilogue is fused: bias, activation, residual add, dual-dtype stores, transposed "V^T" scatter.
 #pragma once
 #include <cstdlib>
 
 #include "common.hpp"
+#include "sched.hpp"
 #include "../../include/fdm_hip.h"
 
 namespace fdm {
@@ -25,7 +27,7 @@ namespace fdm {
 // producer side's per-fragment (sum, sum of squares) pairs [BN / 16][BM][2] live INSIDE the ring (free after the k
 // loop), behind the area of the transposed V tile.
 template <int BM, int BN> constexpr int gemm_ln_scratch_bytes() { return BM * 2 * 4; }
-template <typename T, int BM, int BN> constexpr int gemm_epi_ring_bytes() { return BM * BN * (int)sizeof(T) + BM * 2 * (BN / 16) * 4; }
+template <typename T, int BM, int BN> constexpr int gemm_epi_ring_bytes() { return BM * BN * (int)sizeof(typename Opnd<T>::KV) + BM * 2 * (BN / 16) * 4; }
 
 // Consumer side: mu / rstd of the block's rows from the producer's per-64-column partial sums (fixed order).
 template <int BM>
@@ -98,7 +100,7 @@ __device__ __forceinline__ void gemm_epi_preload(const fdm_gemm_args& p, int m0,
 template <bool HEAVY, typename T> __device__ __forceinline__ float gemm_act(float v, int act) {
   if constexpr (!HEAVY) {
     return act == ACT_RELU ? fmaxf(v, 0.f) : (act == ACT_LEAKY02 ? (v > 0.f ? v : 0.2f * v) : v);
-  } else if constexpr (sizeof(T) == 2) {
+  } else if constexpr (std::is_same<T, bf16>::value) {
     // bf16 (throughput) mode: hardware exp / log forms, ~1e-6 relative -- far inside the bf16 operand rounding
     if (act == ACT_MISH) {
       const float sp = v > 20.f ? v : __logf(1.f + __expf(v));
@@ -110,7 +112,7 @@ template <bool HEAVY, typename T> __device__ __forceinline__ float gemm_act(floa
     }
     return act_apply(v, act);
   } else {
-    return act_apply(v, act);     // fp32 (parity) mode: accurate libm forms
+    return act_apply(v, act);     // fp32 and split (parity) modes: accurate libm forms
   }
 }
 __host__ __device__ inline bool gemm_act_is_heavy(int act) { return act == ACT_MISH || act == ACT_GELU_ERF || act == ACT_GELU_TANH; }
@@ -120,14 +122,16 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
                                               const EpiPre<BM / WM / 16, BN / WN / 16>& e, int m0, int n0, int z,
                                               int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  using E = typename Opnd<T>::E;      // element type of out_t (split kinds: two planes of it)
+  using KV = typename Opnd<T>::KV;    // element type of the packed K / V outputs
   const int M = p.M, N = p.N;
   // Whole-tile packed-V fast path: stage the tile transposed in LDS ([n][m], the ring is free after the k loop) and
   // store 16-byte runs of consecutive keys (one packed chunk each).  Needs the tile to lie entirely in the V columns
-  // and clip boundaries on 16-byte multiples (L % (16 / sizeof(T)) == 0); otherwise the per-element scatter is used.
-  constexpr int EPC_T = 16 / (int)sizeof(T);
+  // and clip boundaries on 16-byte multiples (L % (16 / sizeof(KV)) == 0); otherwise the per-element scatter is used.
+  constexpr int EPC_T = 16 / (int)sizeof(KV);
   const bool vt_tile = tile_lds && p.out_vp && n0 >= p.vp_col0 && n0 + BN <= N && (p.kv_L % EPC_T == 0);
-  T* tl = (T*)tile_lds;
-  float* comb = tile_lds ? (float*)(tile_lds + BM * BN * (int)sizeof(T)) : nullptr;
+  KV* tl = (KV*)tile_lds;
+  float* comb = tile_lds ? (float*)(tile_lds + BM * BN * (int)sizeof(KV)) : nullptr;
   const bool use_ln = rowstat && p.ln_stat_in;
   const bool do_stat = rowstat && comb && p.stat_out;
   if (vt_tile || do_stat) __syncthreads();      // every wave is done reading the last ring stage
@@ -135,7 +139,8 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
   const size_t ocol = (size_t)z * p.out_batch_stride;
   const bool vec_f32 = p.out_f32 && (p.ldo_f32 % 4 == 0) && (((uintptr_t)(p.out_f32 + ocol)) % 16 == 0);
-  const bool vec_t = p.out_t && (p.ldo_t % 4 == 0) && (((uintptr_t)((T*)p.out_t + ocol)) % (4 * sizeof(T)) == 0);
+  const bool vec_t = p.out_t && (p.ldo_t % 4 == 0) && (((uintptr_t)((E*)p.out_t + ocol)) % (4 * sizeof(E)) == 0) &&
+                     (Opnd<T>::NP == 1 || p.out_t_lo_off % 4 == 0);
   const bool vec_r = p.resid && (p.ldr % 4 == 0) && (((uintptr_t)(p.resid + ocol)) % 16 == 0);
   const int kv_H = p.out_vp ? (N - p.vp_col0) / p.kv_hd : 0;
   const size_t kv_blk = (size_t)p.kv_Lpad * p.kv_hd;        // elements per (clip, head) block of the packed buffers
@@ -163,13 +168,13 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       if (m >= M) continue;
       const float mu = use_ln ? rowstat[2 * lrow] : 0.f, rs = use_ln ? rowstat[2 * lrow + 1] : 1.f;
       float* o32 = p.out_f32 ? p.out_f32 + ocol + (size_t)m * p.ldo_f32 + ncol : nullptr;
-      T* ot = p.out_t ? (T*)p.out_t + ocol + (size_t)m * p.ldo_t + ncol : nullptr;
-      T* okp = nullptr;
+      E* ot = p.out_t ? (E*)p.out_t + ocol + (size_t)m * p.ldo_t + ncol : nullptr;
+      KV* okp = nullptr;
       int kv_l = 0;
       if (kv_mode == 1) {
         const int kv_b = m / p.kv_L;
         kv_l = m - kv_b * p.kv_L;
-        okp = (T*)p.out_kp + (size_t)kv_b * KH * kv_blk;
+        okp = (KV*)p.out_kp + (size_t)kv_b * KH * kv_blk;
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -194,32 +199,17 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         if (kv_mode == 2) {
           const int nl = wn * (BN / WN) + ni * 16 + 4 * g;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<T>(v[j]);
+          for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<KV>(v[j]);
           continue;
         }
         if (kv_mode == 1) {
           const int cc = ncol + ni * 16 - kcol_lo;
           const int h = cc / p.kv_hd, e2 = cc - h * p.kv_hd;
-          T* dst = okp + (size_t)h * kv_blk + kp_offset<T>(kv_l, e2, p.kv_hd);
-          if constexpr (sizeof(T) == 4) {
-            *(f32x4*)dst = v;
-          } else {
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *(bf16x4*)dst = o;
-          }
+          store_opnd4<KV>(okp + (size_t)h * kv_blk + kp_offset<KV>(kv_l, e2, p.kv_hd), 0, v);
           continue;
         }
         if (o32) *(f32x4*)(o32 + ni * 16) = v;
-        if (ot) {
-          if constexpr (sizeof(T) == 4) {
-            *(f32x4*)(ot + ni * 16) = v;
-          } else {
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *(bf16x4*)(ot + ni * 16) = o;
-          }
-        }
+        if (ot) store_opnd4<T>(ot + ni * 16, p.out_t_lo_off, v);
       }
     }
   } else {
@@ -284,7 +274,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       if (vt_tile) {
         const int nl = wn * (BN / WN) + ni * 16 + 4 * g;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<T>(v[j]);
+        for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<KV>(v[j]);
         continue;
       }
       if (n >= kcol_lo && n < kcol_hi) {
@@ -292,14 +282,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         const int cc = n - kcol_lo;
         const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
         const int KH = (kcol_hi - kcol_lo) / p.kv_hd;
-        T* dst = (T*)p.out_kp + (size_t)(kv_b * KH + h) * kv_blk + kp_offset<T>(kv_l, e, p.kv_hd);
-        if constexpr (sizeof(T) == 4) {
-          *(f32x4*)dst = v;
-        } else {
-          typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-          bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-          *(bf16x4*)dst = o;
-        }
+        store_opnd4<KV>((KV*)p.out_kp + (size_t)(kv_b * KH + h) * kv_blk + kp_offset<KV>(kv_l, e, p.kv_hd), 0, v);
         continue;
       }
       if (p.out_vp && n >= p.vp_col0) {
@@ -307,7 +290,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
           if (n + j >= N) break;
           const int cc = n + j - p.vp_col0;
           const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
-          ((T*)p.out_vp)[(size_t)(kv_b * kv_H + h) * kv_blk + vp_offset<T>(kv_l, e, p.kv_hd)] = from_f32<T>(v[j]);
+          ((KV*)p.out_vp)[(size_t)(kv_b * kv_H + h) * kv_blk + vp_offset<KV>(kv_l, e, p.kv_hd)] = from_f32<KV>(v[j]);
         }
         continue;
       }
@@ -321,18 +304,12 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         }
       }
       if (p.out_t) {
-        T* op = (T*)p.out_t + ocol + (size_t)m * p.ldo_t + n;
+        E* op = (E*)p.out_t + ocol + (size_t)m * p.ldo_t + n;
         if (full && vec_t) {
-          if constexpr (sizeof(T) == 4) {
-            *(f32x4*)op = v;
-          } else {
-            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-            bf16x4 o = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
-            *(bf16x4*)op = o;
-          }
+          store_opnd4<T>(op, p.out_t_lo_off, v);
         } else {
           for (int j = 0; j < 4; ++j)
-            if (n + j < N) op[j] = from_f32<T>(v[j]);
+            if (n + j < N) store_opnd1<T>(op + j, p.out_t_lo_off, v[j]);
         }
       }
     }
@@ -348,7 +325,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       const int b = m / p.kv_L, l = m - b * p.kv_L;
       const int cc = n0 + nl - p.vp_col0;
       const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
-      *(u32x4*)((T*)p.out_vp + (size_t)(b * kv_H + h) * kv_blk + vp_offset<T>(l, e, p.kv_hd)) = *(const u32x4*)(tl + nl * BM + ml);
+      *(u32x4*)((KV*)p.out_vp + (size_t)(b * kv_H + h) * kv_blk + vp_offset<KV>(l, e, p.kv_hd)) = *(const u32x4*)(tl + nl * BM + ml);
     }
   }
   if (do_stat) {
@@ -370,110 +347,8 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   }
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_kernel(const fdm_gemm_args p) {
-  constexpr int EPC = 16 / (int)sizeof(T);   // elements per 16-byte chunk
-  constexpr int BK = 8 * EPC;                // elements of K per k-tile (128 B)
-  constexpr int MI = BM / 32, NI = BN / 32;  // 16x16 MFMA tiles per wave along m, n
-  constexpr int A_CH = BM * 8 / 256, W_CH = BN * 8 / 256;
-  constexpr int BUF = (BM + BN) * 128;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-    const int nv = *p.incr_counter + 1;
-    *p.incr_counter = nv;
-    if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
-  }
-  const int wm = wave >> 1, wn = wave & 1;
-  const int g = lane >> 4, r16 = lane & 15;
-  const int z = blockIdx.z;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const int M = p.M, N = p.N;
-
-  const T* A = (const T*)p.A + (size_t)z * p.a_batch_stride;
-  const T* W = (const T*)p.W + (size_t)z * p.w_batch_stride;
-
-  const char* a_src[A_CH];
-  const char* w_src[W_CH];
-  int a_dst[A_CH], w_dst[W_CH];
-#pragma unroll
-  for (int i = 0; i < A_CH; ++i) {
-    int c = tid + i * 256, row = c >> 3, kc = c & 7;
-    int grow = min(m0 + row, M - 1);
-    a_src[i] = (const char*)(A + (size_t)grow * p.lda) + kc * 16;
-    a_dst[i] = row * 128 + ((kc ^ (row & 7)) << 4);
-  }
-#pragma unroll
-  for (int i = 0; i < W_CH; ++i) {
-    int c = tid + i * 256, row = c >> 3, kc = c & 7;
-    int grow = min(n0 + row, N - 1);
-    w_src[i] = (const char*)(W + (size_t)grow * p.ldw) + kc * 16;
-    w_dst[i] = BM * 128 + row * 128 + ((kc ^ (row & 7)) << 4);
-  }
-
-  u32x4 ra[A_CH], rw[W_CH];
-  f32x4 acc[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = p.K / BK;
-#pragma unroll
-  for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i]);
-#pragma unroll
-  for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i]);
-#pragma unroll
-  for (int i = 0; i < A_CH; ++i) *(u32x4*)(smem + a_dst[i]) = ra[i];
-#pragma unroll
-  for (int i = 0; i < W_CH; ++i) *(u32x4*)(smem + w_dst[i]) = rw[i];
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = (kt + 1 < nk);
-    if (more) {
-      const size_t off = (size_t)(kt + 1) * 128;
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) ra[i] = *(const u32x4*)(a_src[i] + off);
-#pragma unroll
-      for (int i = 0; i < W_CH; ++i) rw[i] = *(const u32x4*)(w_src[i] + off);
-    }
-    const char* base = smem + (kt & 1) * BUF;
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 af[MI], wf[NI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        int row = wm * (BM / 2) + mi * 16 + r16;
-        af[mi] = *(const u32x4*)(base + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        int row = wn * (BN / 2) + ni * 16 + r16;
-        wf[ni] = *(const u32x4*)(base + BM * 128 + row * 128 + (((4 * s + g) ^ (row & 7)) << 4));
-      }
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], af[mi]);  // D[row=n][col=m]
-    }
-    if (more) {
-      char* nb = smem + ((kt + 1) & 1) * BUF;
-#pragma unroll
-      for (int i = 0; i < A_CH; ++i) *(u32x4*)(nb + a_dst[i]) = ra[i];
-#pragma unroll
-      for (int i = 0; i < W_CH; ++i) *(u32x4*)(nb + w_dst[i]) = rw[i];
-    }
-    __syncthreads();
-  }
-  EpiPre<BM / 2 / 16, BN / 2 / 16> e;
-  gemm_epi_preload<T, BM, BN, 2, 2>(p, m0, n0, z, wm, wn, g, r16, false, e);
-  gemm_epilogue<T, BM, BN>(p, acc, e, m0, n0, z, wm, wn, g, r16);
-}
-
 // ---------------------------------------------------------------------------------------------------
-// v2 main loop: HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into an NST-stage
+// Main loop: HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into an NST-stage
 // ring, tiles prefetched NST-1 deep, counted s_waitcnt vmcnt (never 0 in steady state), one raw
 // s_barrier per k-tile.  The LDS image of a stage is lane-linear (a wave instruction writes 1 KiB =
 // 8 rows x 128 B), so the bank-conflict swizzle is applied to the SOURCE chunk (slot ^ (row & 7)) and
@@ -489,16 +364,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
+  using E = typename Opnd<T>::E;
+  constexpr int NP = Opnd<T>::NP;                // operand planes (2 for the split kinds: hi, lo)
   constexpr int NW = WM * WN;
   constexpr int ROWB = KCH * 16;                 // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;               // rows written by one wave-wide LDS-DMA instruction
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
-  constexpr int A_IPW = BM / RPI / NW, W_IPW = BN / RPI / NW;     // glds instructions per wave per k-tile
+  constexpr int A_IPW = BM / RPI / NW, W_IPW = BN / RPI / NW;     // glds instructions per wave per k-tile and plane
   static_assert(A_IPW >= 1 && W_IPW >= 1 && MI >= 1 && NI >= 1, "tile too small for the wave grid");
-  constexpr int P = A_IPW + W_IPW;
-  constexpr int STAGE = (BM + BN) * ROWB;
+  constexpr int P = NP * (A_IPW + W_IPW);
+  constexpr int STAGE = NP * (BM + BN) * ROWB;   // [A planes][W planes]
   static_assert(NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>(), "epilogue staging does not fit in the ring");
-  constexpr bool EARLY_READS = (KCH / 4) * (MI + NI) <= 12;     // fragment registers for a whole k-tile
+  constexpr bool EARLY_READS = NP * (KCH / 4) * (MI + NI) <= 12;     // fragment registers for a whole k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
 
@@ -514,10 +391,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   const int z = blockIdx.z;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int M = p.M, N = p.N;
-  const T* A = (const T*)p.A + (size_t)z * p.a_batch_stride;
-  const T* W = (const T*)p.W + (size_t)z * p.w_batch_stride;
+  const E* A = (const E*)p.A + (size_t)z * p.a_batch_stride;
+  const E* W = (const E*)p.W + (size_t)z * p.w_batch_stride;
+  const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);   // bytes hi plane -> lo plane
 
-  // per-lane source pointers (k-tile 0); LDS row groups are wave-uniform.  The LDS image is
+  // per-lane source pointers (k-tile 0, plane 0); LDS row groups are wave-uniform.  The LDS image is
   // lane-linear, so the swizzle sits on the source: lane (row, slot) fetches chunk slot ^ (row % KCH).
   const int lrow = lane / KCH, slot = lane % KCH;
   const char* a_src[A_IPW];
@@ -536,28 +414,54 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
     char* sb = smem + (kt % NST) * STAGE;
     const size_t off = (size_t)kt * ROWB;
 #pragma unroll
-    for (int i = 0; i < A_IPW; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off), (lptr_t)(sb + (wave * A_IPW + i) * 1024), 16, 0, 0);
+    for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-    for (int i = 0; i < W_IPW; ++i)
-      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + off), (lptr_t)(sb + BM * ROWB + (wave * W_IPW + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < A_IPW; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (wave * A_IPW + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < W_IPW; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + off + pl * w_lo), (lptr_t)(sb + (NP * BM + pl * BN) * ROWB + (wave * W_IPW + i) * 1024), 16, 0, 0);
+    }
   };
 
   f32x4 acc[MI][NI];
+  f32x4 accl[NP == 2 ? MI : 1][NP == 2 ? NI : 1];     // split kinds: the two small products (hi.lo + lo.hi), scaled once at the end
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ni = 0; ni < NI; ++ni) {
+      acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (NP == 2) accl[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
   EpiPre<MI, NI> epre;       // epilogue operands: issued before (= older than) every ring load
   gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, true, epre);
 
-  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int EPC = 16 / (int)sizeof(E);
   const int nk = p.K / (KCH * EPC);
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) issue(t);
   gemm_load_rowstats<BM>(p, m0, rowstat);   // visible to every wave after the first barrier of the k loop
+
+  // fragment (plane pl, k-step s) of tile row `row` in the stage at `base`: one ds_read_b128 through the XOR swizzle
+  auto frag_a = [&](const char* base, int pl, int s, int mi) {
+    const int row = wm * (BM / WM) + mi * 16 + r16;
+    return *(const u32x4*)(base + (pl * BM + row) * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+  };
+  auto frag_w = [&](const char* base, int pl, int s, int ni) {
+    const int row = wn * (BN / WN) + ni * 16 + r16;
+    return *(const u32x4*)(base + (NP * BM + pl * BN + row) * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+  };
+  auto mma = [&](int mi, int ni, const u32x4 (&wf)[NP], const u32x4 (&af)[NP]) {
+    if constexpr (NP == 1) {
+      Mma<T>::run(acc[mi][ni], wf[0], af[0]);            // D[row = n][col = m]
+    } else {
+      mma16<E>(acc[mi][ni], wf[0], af[0]);
+      mma16<E>(accl[mi][ni], wf[0], af[1]);
+      mma16<E>(accl[mi][ni], wf[1], af[0]);
+    }
+  };
 
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most the (NST-2) younger tiles of this wave are still in flight
@@ -569,48 +473,48 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
       // fragment reads first, THEN the LDS-DMA issue for tile kt+NST-1: a DMA piece costs the issuing wave 60-180
       // cycles (MI355X_MICROARCH.md) which now overlap the ds_read latency instead of preceding it (measured -3..-7 %).
       // (Going further -- reading tile kt+1's fragments before tile kt's MFMAs, two register sets -- measured slower.)
-      u32x4 af[KCH / 4][MI], wf[KCH / 4][NI];
+      u32x4 af[KCH / 4][MI][NP], wf[KCH / 4][NI][NP];
 #pragma unroll
-      for (int s = 0; s < KCH / 4; ++s) {
+      for (int s = 0; s < KCH / 4; ++s)
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int row = wm * (BM / WM) + mi * 16 + r16;
-          af[s][mi] = *(const u32x4*)(base + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+        for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) af[s][mi][pl] = frag_a(base, pl, s, mi);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) wf[s][ni][pl] = frag_w(base, pl, s, ni);
         }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int row = wn * (BN / WN) + ni * 16 + r16;
-          wf[s][ni] = *(const u32x4*)(base + BM * ROWB + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
-        }
-      }
       if (kt + NST - 1 < nk) issue(kt + NST - 1);
 #pragma unroll
       for (int s = 0; s < KCH / 4; ++s)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[s][ni], af[s][mi]);
+          for (int ni = 0; ni < NI; ++ni) mma(mi, ni, wf[s][ni], af[s][mi]);
     } else {
       if (kt + NST - 1 < nk) issue(kt + NST - 1);
 #pragma unroll
       for (int s = 0; s < KCH / 4; ++s) {
-        u32x4 af[MI], wf[NI];
+        u32x4 af[MI][NP], wf[NI][NP];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int row = wm * (BM / WM) + mi * 16 + r16;
-          af[mi] = *(const u32x4*)(base + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
-        }
+        for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          const int row = wn * (BN / WN) + ni * 16 + r16;
-          wf[ni] = *(const u32x4*)(base + BM * ROWB + row * ROWB + (((4 * s + g) ^ (row % KCH)) << 4));
+          for (int mi = 0; mi < MI; ++mi) af[mi][pl] = frag_a(base, pl, s, mi);
+#pragma unroll
+          for (int ni = 0; ni < NI; ++ni) wf[ni][pl] = frag_w(base, pl, s, ni);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) Mma<T>::run(acc[mi][ni], wf[ni], af[mi]);
+          for (int ni = 0; ni < NI; ++ni) mma(mi, ni, wf[ni], af[mi]);
       }
     }
+  }
+  if constexpr (NP == 2) {
+    constexpr float inv = 1.f / Opnd<T>::SCALE;      // a power of two: exact
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += accl[mi][ni] * inv;
   }
   gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 }
@@ -618,7 +522,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
-  constexpr int lds = NST * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
+  constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
+  static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
   static bool once = [] {
     return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();
@@ -632,19 +537,10 @@ static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
                                   : gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false>(a, s);
 }
 
-template <typename T, int BM, int BN>
-static hipError_t gemm_launch_t(const fdm_gemm_args& a, hipStream_t s) {
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
-  const int lds = 2 * (BM + BN) * 128;
-  hipLaunchKernelGGL((gemm_kernel<T, BM, BN>), grid, dim3(256), lds, s, a);
-  return hipGetLastError();
-}
-
-// Tile choice.  FDM_GEMM_VARIANT (env, read once) selects a kernel family for A/B measurements:
-//   0 = v1 register-staged double buffer (64x64 / 128x128), 1 = v2 LDS-DMA ring (default), 2..5 = ring with tile
-//   FDM_TILE_* = value - 1 forced for every GEMM.
-static int gemm_variant() {
-  static int v = [] { const char* e = getenv("FDM_GEMM_VARIANT"); return e ? atoi(e) : 1; }();
+// Tile choice: fdm_gemm_args.tile (the caller's plan-time choice), else the FDM_GEMM_TILE override (env, read once: the
+// FDM_TILE_* value forced for every GEMM, for A/B measurements), else a heuristic on the tile count.
+static int gemm_tile_override() {
+  static int v = [] { const char* e = getenv("FDM_GEMM_TILE"); return e ? atoi(e) : 0; }();
   return v;
 }
 
@@ -652,13 +548,8 @@ template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   const long long batch = a.batch > 0 ? a.batch : 1;
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
-  if (gemm_variant() == 0) {
-    if (a.stat_out || a.ln_stat_in) return hipErrorInvalidValue;      // LayerNorm folding lives in the ring kernels only
-    return t128 >= 384 ? gemm_launch_t<T, 128, 128>(a, s) : gemm_launch_t<T, 64, 64>(a, s);
-  }
   if (a.sched_fuse) return gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true>(a, s);    // (validated: interior tiles only)
-  // explicit tile (fdm_gemm_args.tile, chosen by the caller's plan-time tuning) or the A/B override
-  switch (a.tile > 0 ? a.tile : (gemm_variant() > 1 ? gemm_variant() - 1 : 0)) {
+  switch (a.tile > 0 ? a.tile : gemm_tile_override()) {
     case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);      // 8 waves, 32x16 per wave
     case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
     case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);  // 8 waves, 64x32 per wave
@@ -680,8 +571,33 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                       // 8 waves, 32x16 per wave
 }
 
-static hipError_t gemm_launch(const fdm_gemm_args& a, hipStream_t s) {
-  return a.dtype == FDM_BF16 ? gemm_dispatch<bf16>(a, s) : gemm_dispatch<float>(a, s);
+// Split kinds: a ring stage is twice as large (hi and lo planes of both operands), so the tile set is the part of the
+// one above whose ring fits 160 KB of LDS; other FDM_TILE_* values map to the nearest member.
+template <typename T>
+static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
+  const long long batch = a.batch > 0 ? a.batch : 1;
+  if (a.sched_fuse) return gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true>(a, s);
+  if constexpr (std::is_same<T, bf16x3_t>::value) {
+    return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                          // comparison mode: one tile
+  } else {
+    switch (a.tile > 0 ? a.tile : gemm_tile_override()) {
+      case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);     // 128 KB ring
+      case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);  // 96 KB
+      case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);  // 64 KB -> 2 workgroups per CU
+      case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
+      case FDM_TILE_128x64:
+      case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);   // 144 KB
+      case FDM_TILE_128x128:
+      case FDM_TILE_96x128:
+      case FDM_TILE_256x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);    // 128 KB, one tile in flight
+      default: break;
+    }
+    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
+    const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
+    if (t128 >= 512) return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);
+    if (t128x64 >= 700) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);
+    return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);
+  }
 }
 
 }  // namespace fdm

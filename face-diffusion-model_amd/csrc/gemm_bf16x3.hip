@@ -1,0 +1,4 @@
+// GEMM kernels for split bf16x3 operands (see gemm.hpp, common.hpp Opnd<>).
+#include "gemm.hpp"
+#include "kernels.hpp"
+namespace fdm { hipError_t gemm_launch_bf16x3(const fdm_gemm_args& a, hipStream_t s) { return gemm_dispatch_split<bf16x3_t>(a, s); } }

@@ -6,7 +6,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfdm_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16X3, BF16X3 = 0, 1, 2, 3      # include/fdm_hip.h FDM_*: operand kinds (the last two are split plane pairs)
+DTYPE_NAMES = {"f32": F32, "bf16": BF16, "f16x3": F16X3, "bf16x3": BF16X3}
 ACT_NONE, ACT_RELU, ACT_MISH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02 = range(6)
 
 vp, ll, ci, cf = C.c_void_p, C.c_longlong, C.c_int, C.c_float
@@ -18,7 +19,7 @@ class SchedArgs(C.Structure):
                 ("c1", vp), ("c2", vp), ("sigma", vp), ("sra", vp), ("srm1", vp),
                 ("sqrt_an", vp), ("c_n", vp), ("noise", vp), ("noise_stride", ll), ("x_out_t", vp), ("out_dtype", ci), ("arrive", vp),
                 ("seed", C.c_ulonglong), ("clip0", ci),
-                ("mode", ci)]
+                ("mode", ci), ("x_out_t_lo_off", ll)]
 
 
 class GemmArgs(C.Structure):
@@ -33,7 +34,8 @@ class GemmArgs(C.Structure):
                 ("kv_L", ci), ("kv_Lpad", ci), ("kv_hd", ci),
                 ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
                 ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci),
-                ("sched_fuse", ci), ("sched", SchedArgs)]
+                ("sched_fuse", ci), ("sched", SchedArgs),
+                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll)]
 
 
 TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -42,13 +44,13 @@ TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TIL
 class AttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("ldq", ll), ("Kp", vp), ("Vp", vp), ("Lpad", ci),
                 ("O", vp), ("ldo", ll), ("B", ci), ("H", ci), ("L", ci), ("hd", ci), ("dtype", ci),
-                ("scale", cf), ("causal", ci), ("slopes", vp), ("period", ci)]
+                ("scale", cf), ("causal", ci), ("slopes", vp), ("period", ci), ("o_split", ci), ("o_lo_off", ll)]
 
 
 class LnArgs(C.Structure):
     _fields_ = [("x", vp), ("M", ci), ("d", ci), ("add_mat", vp), ("add_tab", vp),
                 ("tab_index", vp), ("tab_step", vp), ("gamma", vp), ("beta", vp), ("eps", cf),
-                ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci), ("gamma2", vp), ("beta2", vp)]
+                ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci), ("gamma2", vp), ("beta2", vp), ("y_t_lo_off", ll)]
 
 
 # every symbol include/fdm_hip.h declares: name -> (restype, argtypes)

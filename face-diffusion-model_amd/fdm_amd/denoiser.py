@@ -201,16 +201,21 @@ class DenoiserPlan:
         z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dv, dtype=dt)
         self.Lpad = ops.kv_pad(self.L)
         ws = dict(h=z(R, d), h2=z(R, d), x1=z(R, d), x0=z(R, d), x=z(self.M, d))
-        if self.dtype == BF16:
-            ws.update(xt=z(self.M, d, dt=td), ht=z(R, d, dt=td), h2t=z(R, d, dt=td))
+        split = ops.is_split(self.dtype)
+        # operand-kind matrices (GEMM inputs): plain tensors, or hi/lo plane pairs in the split modes
+        zt = (lambda r, c: ops.Split.empty(r, c, self.dtype, dv)) if split else (lambda r, c: z(r, c, dt=td))
+        if self.dtype != F32:
+            ws.update(xt=zt(self.M, d), ht=zt(R, d), h2t=zt(R, d))
         else:   # fp32 operands alias the fp32 residual-stream buffers
             ws.update(xt=ws["x"], ht=ws["h"], h2t=ws["h2"])
         if self.fuse_ln3:
             ws.update(x2=z(R, d), x2t=z(R, d, dt=td), stats=z(self.chains, d // 64, self.Rc, 2))
         # q: row-major queries; kp / vp: fragment-packed keys / values written by the QKV GEMM's epilogue (zeroed: pad keys)
-        ws.update(q=z(R, d, dt=td), ctx=z(R, d, dt=td), u=z(R, p.ffn, dt=td),
-                  kp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=td),
-                  vp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=td))
+        # (split modes: attention runs in fp32 -- Q / K / V leave the QKV GEMM as fp32, ctx returns as a plane pair)
+        ta = torch.float32 if split else td
+        ws.update(q=z(R, d, dt=ta), ctx=zt(R, d), u=zt(R, p.ffn),
+                  kp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=ta),
+                  vp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=ta))
         self.ws = ws
         # per chain: [device-side step counter, t of the current step]; both written by one thread of the step's first GEMM
         self.step = torch.zeros(2 * self.chains, dtype=torch.int32, device=dv)
@@ -323,7 +328,7 @@ class DenoiserPlan:
         p, d, ws, w, wt = self.p, self.p.d, self.ws, self.w32, self.wt
         Mc, Rc, Bc, L = self.Mc, self.Rc, self.Bc, self.L
         xr, rb = c * Mc, c * Rc                         # first row of the group in x / in the decoder-stack buffers
-        both = self.dtype == BF16
+        both = self.dtype != F32
         step, tcur = self.step[2 * c:], self.step[2 * c + 1:]
         # (the operand-dtype copy ws['xt'] of x is written by the scheduler kernel of the previous step and by
         #  _load_x() before the first one)
@@ -336,8 +341,11 @@ class DenoiserPlan:
             # (first kernel of the step: step counter += 1, tcur = tseq[step])
         BBc = Bc * self.rep
         kp, vp = ws["kp"][c * BBc * p.n_head:], ws["vp"][c * BBc * p.n_head:]
-        kv = dict(out_t=ws["q"][rb:], ldo_t=d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=self.Lpad,
-                  kv_hd=p.head_dim)
+        kv = dict(out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=self.Lpad, kv_hd=p.head_dim)
+        if ops.is_split(self.dtype):
+            kv.update(out_f32=ws["q"][rb:], ldo_f32=d)
+        else:
+            kv.update(out_t=ws["q"][rb:], ldo_t=d)
         fuse = self.fuse_ln3
         st = ws["stats"][c] if fuse else None
         np_, eps = d // 64, 1e-5
@@ -401,7 +409,7 @@ class DenoiserPlan:
                 x0 = ws["x0"][c * Rc:]
                 x0u = ws["x0"][c * Rc + Mc:] if self.cfg else None
                 x = ws["x"][c * Mc:]
-                xt = ws["xt"][c * Mc:] if self.dtype == BF16 else None
+                xt = ws["xt"][c * Mc:] if self.dtype != F32 else None
                 step = self.step[2 * c:]
                 skw = None
                 if kind == "ddpm":
@@ -448,7 +456,7 @@ class DenoiserPlan:
 
     def _load_x(self, x):
         self.ws["x"].copy_(x.reshape(self.M, self.p.d))
-        if self.dtype == BF16:
+        if self.dtype != F32:
             ops.cast(self.ws["x"], self.ws["xt"])
 
     def _run(self, prog, n_steps, use_graph):

@@ -8,8 +8,45 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32,
+from ._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, BF16X3, F16X3, F32,
                    AttnArgs, GemmArgs, LnArgs, SchedArgs, check, lib)
+
+
+class Split:
+    """A split-precision GEMM operand (include/fdm_hip.h, FDM_F16X3 / FDM_BF16X3): planes[0] = hi, planes[1] = lo of a
+    [rows, cols] matrix held in one [2, rows, cols] 16-bit tensor.  Slicing rows ([r0:]) keeps the plane distance."""
+
+    def __init__(self, planes, code, row0=0):
+        self.planes, self.code, self.row0 = planes, code, row0
+        self.lo_off = planes[0].numel()
+
+    @classmethod
+    def empty(cls, rows, cols, code, device):
+        return cls(torch.zeros(2, rows, cols, device=device, dtype=tdtype(code)), code)
+
+    def __getitem__(self, sl):
+        if not isinstance(sl, slice) or sl.stop is not None or sl.step is not None:
+            raise _lib.FdmError("Split operands support [r0:] row offsets only")
+        return Split(self.planes, self.code, self.row0 + (sl.start or 0))
+
+    @property
+    def is_cuda(self):
+        return self.planes.is_cuda
+
+    @property
+    def shape(self):
+        return self.planes.shape[1:]
+
+    def data_ptr(self):
+        return self.planes.data_ptr() + self.row0 * self.planes.shape[2] * self.planes.element_size()
+
+    def numel(self):
+        return self.lo_off
+
+    def float(self):
+        """hi + lo / SCALE as fp32 (tests)."""
+        sc = 2048.0 if self.code == F16X3 else 1.0
+        return (self.planes[0].float() + self.planes[1].float() / sc)[self.row0:]
 
 
 def _p(t):
@@ -20,15 +57,26 @@ def _p(t):
     return t.data_ptr()
 
 
+def _lo(t):
+    return t.lo_off if isinstance(t, Split) else 0
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
 def tdtype(code):
-    return torch.bfloat16 if code == BF16 else torch.float32
+    """torch dtype of the elements of operand kind `code` (split kinds: of each plane)."""
+    return {BF16: torch.bfloat16, BF16X3: torch.bfloat16, F16X3: torch.float16}.get(code, torch.float32)
+
+
+def is_split(code):
+    return code in (F16X3, BF16X3)
 
 
 def code_of(t):
+    if isinstance(t, Split):
+        return t.code
     if t.dtype == torch.bfloat16:
         return BF16
     if t.dtype == torch.float32:
@@ -45,8 +93,9 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
     a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
     a.M, a.N, a.K, a.batch, a.dtype = M, N, K, batch, code_of(A)
-    if W.dtype != A.dtype:
-        raise _lib.FdmError("gemm: A and W dtypes differ")
+    if code_of(W) != a.dtype:
+        raise _lib.FdmError("gemm: A and W operand kinds differ")
+    a.a_lo_off, a.w_lo_off, a.out_t_lo_off = _lo(A), _lo(W), _lo(out_t)
     a.bias, a.bias_batch_stride, a.act = _p(bias), bias_bs, act
     a.resid, a.ldr, a.resid_row_mod = _p(resid), (ldr if ldr is not None else N), resid_row_mod
     a.out_f32, a.ldo_f32 = _p(out_f32), (ldo_f32 if ldo_f32 is not None else N)
@@ -83,6 +132,8 @@ def attention(Q, Kp, Vp, O, *, B, H, L, hd, ldq, ldo, Lpad, scale, causal=False,
     a = AttnArgs()
     a.Q, a.ldq, a.Kp, a.Vp, a.Lpad = _p(Q), ldq, _p(Kp), _p(Vp), Lpad
     a.O, a.ldo, a.B, a.H, a.L, a.hd, a.dtype = _p(O), ldo, B, H, L, hd, code_of(Q)
+    if isinstance(O, Split):       # fp32 attention writing the next GEMM's split operand
+        a.o_split, a.o_lo_off = O.code, O.lo_off
     a.scale, a.causal, a.slopes, a.period = scale, int(causal), _p(slopes), period
     check(lib().fdm_op_attention(C.byref(a), stream()))
 
@@ -93,7 +144,7 @@ def layernorm(x, gamma, beta, M, d, *, add_mat=None, add_tab=None, tab_index=Non
     a.x, a.M, a.d, a.add_mat, a.add_tab = _p(x), M, d, _p(add_mat), _p(add_tab)
     a.tab_index, a.tab_step, a.gamma, a.beta, a.eps = _p(tab_index), _p(tab_step), _p(gamma), _p(beta), eps
     a.act, a.y_f32, a.y_t, a.dtype = act, _p(y_f32), _p(y_t), dtype
-    a.gamma2, a.beta2 = _p(gamma2), _p(beta2)
+    a.gamma2, a.beta2, a.y_t_lo_off = _p(gamma2), _p(beta2), _lo(y_t)
     check(lib().fdm_op_layernorm(C.byref(a), stream()))
 
 
@@ -108,6 +159,7 @@ def sched_args(mode, x0, x, x_out, n, *, x0u=None, cfg_scale=0.0, n_per_clip=0, 
     a.sqrt_an, a.c_n, a.noise, a.noise_stride = _p(sqrt_an), _p(c_n), _p(noise), noise_stride
     a.seed, a.clip0, a.mode = seed, clip0, mode
     a.x_out_t, a.out_dtype, a.arrive = _p(x_out_t), (code_of(x_out_t) if x_out_t is not None else 0), _p(arrive)
+    a.x_out_t_lo_off = _lo(x_out_t)
     return a
 
 
@@ -121,10 +173,13 @@ def cast(src, dst):
 
 
 def to_operand(src_f32, dtype):
-    """fp32 device tensor -> operand dtype copy (identity for fp32)."""
+    """fp32 device matrix -> operand-kind copy (identity for fp32; a Split plane pair for the split kinds)."""
     if dtype == F32:
         return src_f32
-    dst = torch.empty(src_f32.shape, dtype=torch.bfloat16, device=src_f32.device)
+    if is_split(dtype):
+        dst = Split(torch.empty((2,) + tuple(src_f32.shape), dtype=tdtype(dtype), device=src_f32.device), dtype)
+    else:
+        dst = torch.empty(src_f32.shape, dtype=torch.bfloat16, device=src_f32.device)
     cast(src_f32.contiguous(), dst)
     return dst
 

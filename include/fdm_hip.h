@@ -23,6 +23,14 @@ extern "C" {
 
 #define FDM_F32 0
 #define FDM_BF16 1
+/* Split operands (GEMM inputs only): x = hi + lo / S held as two planes of a 16-bit type, the lo plane `*_lo_off`
+ * ELEMENTS after the hi plane, and the product evaluated as hi.hi + (hi.lo + lo.hi) / S in three passes of the 16-bit
+ * MFMA with fp32 accumulation.  FDM_F16X3: fp16 planes, S = 2^11 (22 significant bits per operand: fp32-class results,
+ * the mode that meets the 1e-4 contract on the 16-bit matrix cores; |x| is clamped to 65504).  FDM_BF16X3: bf16 planes,
+ * S = 1 (16 bits per operand; ~5e-5 per denoiser call -- kept for comparison).  In these modes the QKV projection
+ * writes fp32 Q / packed K / V (attention runs in fp32) and every producer of a GEMM input writes the plane pair. */
+#define FDM_F16X3 2
+#define FDM_BF16X3 3
 
 #define FDM_ACT_NONE 0
 #define FDM_ACT_RELU 1       /* nn.TransformerDecoderLayer default activation, models/fdm_vocaset.py:45 */
@@ -66,6 +74,7 @@ typedef struct fdm_sched_args {
                                                                 advance it inside this kernel (no separate launch) */
   unsigned long long seed; int clip0;
   int mode;                                                  /* 0 DDPM, 1 DDIM, 2 CFG mix only (x_out = mix) */
+  long long x_out_t_lo_off;                                  /* split out_dtype: elements between the hi and lo planes of x_out_t */
 } fdm_sched_args;
 int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
 
@@ -78,12 +87,13 @@ int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
  * and/or operand-dtype copies.  For a fused QKV projection the K columns [kp_col0, vp_col0) and the
  * V columns [vp_col0, N) can be written straight into the attention kernel's fragment-packed
  * buffers (see fdm_attn_args) instead of out_t/out_f32.  K must be a multiple of 32 (fp32) /
- * 64 (bf16); A, W 16-byte aligned with lda, ldw multiples of 4 (fp32) / 8 (bf16).            */
+ * 64 (16-bit kinds); A, W 16-byte aligned with lda, ldw multiples of 4 (fp32) / 8 (16-bit kinds).   */
 typedef struct fdm_gemm_args {
   const void* A; long long lda; long long a_batch_stride;
   const void* W; long long ldw; long long w_batch_stride;
   int M, N, K, batch;
-  int dtype;                      /* FDM_F32 | FDM_BF16: type of A, W, out_t, out_kp, out_vp */
+  int dtype;                      /* FDM_F32 | FDM_BF16: type of A, W, out_t, out_kp, out_vp;
+                                     FDM_F16X3 | FDM_BF16X3: A, W, out_t are split plane pairs, out_kp / out_vp fp32 */
   const float* bias; long long bias_batch_stride;
   int act;
   const float* resid; long long ldr; int resid_row_mod;
@@ -120,6 +130,8 @@ typedef struct fdm_gemm_args {
    * N % 64 == 0, ldo_f32 == ldr == N, 16-byte aligned pointers; sched.x0 / x0u / x / x_out / x_out_t / arrive unused. */
   int sched_fuse;
   fdm_sched_args sched;
+  /* split operand kinds (dtype FDM_F16X3 / FDM_BF16X3): elements between the hi and lo planes of A, W and out_t */
+  long long a_lo_off, w_lo_off, out_t_lo_off;
 } fdm_gemm_args;
 #define FDM_TILE_AUTO 0
 #define FDM_TILE_64x64 1
@@ -160,6 +172,9 @@ typedef struct fdm_attn_args {
   int causal;
   const float* slopes;   /* [H] device floats or NULL */
   int period;
+  /* o_split = FDM_F16X3 / FDM_BF16X3 (with dtype FDM_F32): O is written as a split plane pair (the next GEMM's input),
+   * lo plane o_lo_off elements after the hi plane; 0 = O has the dtype of Q */
+  int o_split; long long o_lo_off;
 } fdm_attn_args;
 int fdm_op_attention(const fdm_attn_args* a, void* stream);
 /* row-major K, V (row b*L + l, column h*hd + e, row strides ldk / ldv) -> the packed layouts above */
@@ -184,13 +199,14 @@ typedef struct fdm_ln_args {
    * models/fdm_vocaset.py:45): y = LN2(LN1(x) + add_mat + add_tab[idx]); the addends then belong to
    * stage 2 and stage 1 sees x alone. */
   const float* gamma2; const float* beta2;
+  long long y_t_lo_off;               /* split dtype: elements between the hi and lo planes of y_t */
 } fdm_ln_args;
 int fdm_op_layernorm(const fdm_ln_args* a, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------
  * Small elementwise / layout operators.                                                      */
-/* dst_t[i] = (dtype) src_f32[i] */
+/* dst_t[i] = (dtype) src_f32[i]; split dtypes: hi plane at dst, lo plane at dst + n elements */
 int fdm_op_cast(const float* src, void* dst, long long n, int dtype, void* stream);
 /* out[r, :] = act(in[r, :] + vec[:]) -- e.g. tau table = Mish(W_t^T + b_t), models/fdm_vocaset.py:71-72 */
 int fdm_op_bias_act(const float* in, const float* vec, float* out, long long rows, int d, int act, void* stream);

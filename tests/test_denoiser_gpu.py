@@ -10,13 +10,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from fdm_amd.denoiser import DenoiserPlan  # noqa: E402
-from fdm_amd._lib import BF16, F32  # noqa: E402
+from fdm_amd._lib import BF16, BF16X3, F16X3, F32  # noqa: E402
 from oracle import fdm_oracle as FO  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
 DEV = "cuda:0"
 TOL32 = 1e-4
 TOLBF = 8e-2
+# the modes that meet the contract tolerance (BASELINE.json: 1e-4 max-abs vs the reference): exact fp32 MFMA, and split-fp16
+# operands on the 16-bit matrix cores (three MFMA passes per product, 22 significant bits per operand)
+PARITY_MODES = [F32, F16X3]
 
 
 def mad(a, b):
@@ -33,10 +36,11 @@ def plan_for(preset, dtype):
     return _PLANS[key]
 
 
+@pytest.mark.parametrize("dtype", PARITY_MODES)
 @pytest.mark.parametrize("preset", ["vocaset_tiny", "mead_tiny", "vocaset", "mead"])
-def test_single_step_vs_golden_fp32(golden, preset):
+def test_single_step_vs_golden_fp32(golden, preset, dtype):
     g = golden(f"fdm_step_{preset}")
-    plan, _ = plan_for(preset, F32)
+    plan, _ = plan_for(preset, dtype)
     for (L, t) in g["cases"].tolist():
         inp = W.synth_inputs(preset, 1, L, seed=100 + L)
         plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
@@ -55,11 +59,31 @@ def test_single_step_bf16_stated_tolerance(golden, preset):
         assert mad(out[0], g[f"x0_L{L}_t{t}"]) < TOLBF, (preset, L, t)
 
 
+def test_bf16x3_split_is_short_of_the_contract_f16x3_is_not(golden):
+    """Why the split mode uses fp16 planes: with bf16 planes (8 bits each, 16 per operand) one full-size denoiser call is
+    already ~5e-5 from the reference (a 50-step chain exceeds 1e-4), with fp16 planes (11 + 11 bits) it is at the fp32
+    kernel's own distance."""
+    g = golden("fdm_step_vocaset")
+    err = {}
+    for dt in (F32, F16X3, BF16X3):
+        plan, _ = plan_for("vocaset", dt)
+        e = 0.0
+        for (L, t) in g["cases"].tolist():
+            inp = W.synth_inputs("vocaset", 1, L, seed=100 + L)
+            plan.prepare(inp["hub"], inp["style"], L=L)
+            e = max(e, mad(plan.denoise(inp["x"].to(DEV), t)[0], g[f"x0_L{L}_t{t}"]))
+        err[dt] = e
+    print(f"max-abs vs reference goldens: f32 {err[F32]:.2e}  f16x3 {err[F16X3]:.2e}  bf16x3 {err[BF16X3]:.2e}")
+    assert err[F16X3] < 3 * max(err[F32], 5e-6) and err[F16X3] < TOL32
+    assert err[BF16X3] < 1e-3 and err[BF16X3] > 2 * err[F16X3]
+
+
+@pytest.mark.parametrize("dtype", PARITY_MODES)
 @pytest.mark.parametrize("preset", ["vocaset_tiny", "vocaset", "mead"])
-def test_chains_vs_golden_fp32(golden, preset):
+def test_chains_vs_golden_fp32(golden, preset, dtype):
     """DDPM t=9..0 and 999..990 with injected noise (after every step), DDIM 3 and 50 steps."""
     g = golden(f"chains_{preset}")
-    plan, _ = plan_for(preset, F32)
+    plan, _ = plan_for(preset, dtype)
     L = int(g["L"])
     inp = W.synth_inputs(preset, 1, L, seed=7)
     plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
@@ -79,9 +103,10 @@ def test_chains_vs_golden_fp32(golden, preset):
             assert mad(out, g[f"ddim_{steps}_final"]) < TOL32, steps
 
 
-def test_cfg_two_pass_mix_vs_golden(golden):
+@pytest.mark.parametrize("dtype", PARITY_MODES)
+def test_cfg_two_pass_mix_vs_golden(golden, dtype):
     g = golden("cfg_mead")
-    plan, _ = plan_for("mead", F32)
+    plan, _ = plan_for("mead", dtype)
     L, t = int(g["L"]), int(g["t"])
     inp = W.synth_inputs("mead", 1, L, seed=55)
     plan.prepare(inp["hub"], inp["style"], inp["emo"], L=L, cfg=True)
@@ -90,7 +115,7 @@ def test_cfg_two_pass_mix_vs_golden(golden):
     assert mad(plan.ws["x0"][plan.Mc:plan.Rc].reshape(-1, 64), g["uncond"]) < TOL32
 
 
-@pytest.mark.parametrize("preset,dtype", [("vocaset", F32), ("mead", F32), ("vocaset", BF16)])
+@pytest.mark.parametrize("preset,dtype", [("vocaset", F32), ("mead", F32), ("vocaset", BF16), ("vocaset", F16X3), ("mead", F16X3)])
 def test_batched_clips_equal_independent_b1_calls(preset, dtype):
     """B > 1 == independent B = 1 reference calls; results do not depend on batch composition."""
     plan, w = plan_for(preset, dtype)
@@ -99,7 +124,7 @@ def test_batched_clips_equal_independent_b1_calls(preset, dtype):
     plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
     out = plan.denoise(inp["x"].to(DEV), t).cpu()
     ref = FO.fdm_forward(w, preset, inp["hub"], t, inp["x"], inp["style"], inp.get("emo"), folded=True)
-    assert mad(out, ref) < (TOL32 if dtype == F32 else TOLBF)
+    assert mad(out, ref) < (TOLBF if dtype == BF16 else TOL32)
     for b in (0, 2):
         plan.prepare(inp["hub"][b:b + 1], inp["style"][b:b + 1], None if "emo" not in inp else inp["emo"][b:b + 1], L=L)
         one = plan.denoise(inp["x"][b:b + 1].to(DEV), t).cpu()
@@ -207,7 +232,7 @@ def test_full_size_cfg2_chain_properties():
     ts = list(range(T - 1, -1, -1))
     xT = inp["x"].to(DEV)
     outs = {}
-    for dt in (F32, BF16):
+    for dt in (F32, BF16, F16X3):
         plan, _ = plan_for("vocaset", dt)
         plan.prepare(inp["hub"], inp["style"], L=L)
         a = plan.sample_ddpm(xT, ts, seed=1234)
@@ -224,11 +249,13 @@ def test_full_size_cfg2_chain_properties():
             assert torch.equal(one[0], outs[F32][2]), "clip result depends on the batch it was sampled in"
     d = mad(outs[F32], outs[BF16])
     scale = float(outs[F32].abs().max())
-    print(f"full-size cfg2: |fp32 - bf16| max-abs after 1000 steps = {d:.3e} (latent max {scale:.2f})")
+    d3 = mad(outs[F32], outs[F16X3])
+    print(f"full-size cfg2: max-abs after 1000 steps vs the fp32 program: bf16 {d:.3e}, f16x3 {d3:.3e} (latent max {scale:.2f})")
     assert d < 0.25
+    assert d3 < TOL32, "the split-fp16 program left the contract tolerance over the full chain"
 
 
-@pytest.mark.parametrize("dtype", [F32, BF16])
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
 def test_gemm_tile_choice_changes_speed_not_results(dtype, monkeypatch):
     """Plan-time tile tuning (DenoiserPlan._tune_tiles): every output tile accumulates k in the same order, so forcing
     any tile at every tuned call site gives bit-identical latents; FDM_TUNE=0 (library heuristic) likewise."""
@@ -264,7 +291,7 @@ def test_long_clip_single_step_vs_oracle(preset, L):
     _, w = plan_for(preset, F32)
     t = 321
     ref = FO.fdm_forward(w, preset, inp["hub"], t, inp["x"], inp["style"], inp.get("emo"), folded=True)
-    for dt, tol in ((F32, TOL32), (BF16, TOLBF)):
+    for dt, tol in ((F32, TOL32), (F16X3, TOL32), (BF16, TOLBF)):
         plan, _ = plan_for(preset, dt)
         plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
         assert mad(plan.denoise(inp["x"].to(DEV), t).cpu(), ref) < tol, (preset, L, dt)

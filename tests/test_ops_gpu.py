@@ -10,7 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from fdm_amd import ops  # noqa: E402
-from fdm_amd._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32)  # noqa: E402
+from fdm_amd._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, BF16X3, F16X3, F32)  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -53,6 +53,57 @@ def test_gemm(dtype, M, N, K, act):
     tol = 2e-5 if dtype == F32 else 1e-2
     assert rel(o32, ref) < tol
     assert rel(ot.float(), ref) < (tol if dtype == F32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype,tol", [(F16X3, 2e-6), (BF16X3, 1e-4)])
+@pytest.mark.parametrize("M,N,K,act,tile", [(7, 256, 256, ACT_MISH, 0), (100, 1024, 1024, ACT_NONE, 0), (800, 3072, 1024, ACT_RELU, 0),
+                                            (33, 1500, 1024, ACT_NONE, 6), (257, 192, 2048, ACT_GELU_ERF, 9),
+                                            (1600, 2048, 1024, ACT_NONE, 3), (530, 1024, 2048, ACT_LEAKY02, 2), (800, 1024, 1024, ACT_NONE, 8)])
+def test_gemm_split_operands(dtype, tol, M, N, K, act, tile):
+    """Split-operand GEMMs (hi/lo planes, three 16-bit MFMA passes) against an fp64 product of the SAME fp32 inputs:
+    f16x3 is fp32-class (the fp32 MFMA kernel itself sits at ~1e-6 on this scale), bf16x3 carries 16 bits per operand."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N + 3, generator=g)[:N].contiguous()
+    resid = torch.randn(M, N, generator=g)
+    ref = (act_ref(A.double() @ W.double().t() + bias, act) + resid)
+    As, Ws = ops.to_operand(A.to(DEV), dtype), ops.to_operand(W.to(DEV), dtype)
+    # the plane pairs reproduce the fp32 inputs to 2^-22 (f16x3) / 2^-16 (bf16x3)
+    assert rel(As.float(), A) < (1e-6 if dtype == F16X3 else 1e-4)
+    o32 = torch.zeros(M, N, device=DEV)
+    ot = ops.Split.empty(M, N, dtype, DEV)
+    ops.gemm(As, Ws, M, N, K, bias=bias.to(DEV), act=act, resid=resid.to(DEV), out_f32=o32, out_t=ot, tile=tile)
+    torch.cuda.synchronize()
+    assert rel(o32, ref) < tol
+    assert rel(ot.float(), o32) < (1e-6 if dtype == F16X3 else 1e-4)      # the output plane pair round-trips the fp32 result
+    # tile choice changes speed only: identical bits from another tile
+    if dtype == F16X3:
+        o2 = torch.zeros(M, N, device=DEV)
+        ops.gemm(As, Ws, M, N, K, bias=bias.to(DEV), act=act, resid=resid.to(DEV), out_f32=o2, tile=1)
+        assert torch.equal(o2, o32)
+
+
+def test_split_producers_write_plane_pairs():
+    """LayerNorm, scheduler and fp32 attention write GEMM inputs as plane pairs in the split modes."""
+    g = torch.Generator().manual_seed(3)
+    M, d = 37, 1024
+    x = torch.randn(M, d, generator=g)
+    gam, bet = torch.randn(d, generator=g), torch.randn(d, generator=g)
+    y32 = torch.zeros(M, d, device=DEV)
+    yt = ops.Split.empty(M + 5, d, F16X3, DEV)
+    ops.layernorm(x.to(DEV), gam.to(DEV), bet.to(DEV), M, d, y_f32=y32, y_t=yt[5:], dtype=F16X3)
+    assert rel(yt.float()[5:], y32) < 1e-6 and rel(y32, F.layer_norm(x, (d,), gam, bet)) < 1e-5
+    n = M * d
+    x0, xx = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    c = torch.rand(4, generator=g)
+    xo = torch.zeros(n, device=DEV)
+    xot = ops.Split.empty(M, d, F16X3, DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    tseq = torch.tensor([2], dtype=torch.int32, device=DEV)
+    ops.sched_step(0, x0.to(DEV), xx.to(DEV), xo, n, tseq=tseq, step=step, c1=c.to(DEV), c2=c.to(DEV), sigma=c.to(DEV),
+                   noise=torch.zeros(n, device=DEV), x_out_t=xot)
+    assert rel(xot.float().reshape(-1), xo) < 1e-6
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16])
