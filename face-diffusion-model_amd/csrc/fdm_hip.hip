@@ -14,10 +14,9 @@
 #include "elementwise.hpp"
 #include "kernels.hpp"
 
-namespace {
-
+namespace fdm {
 thread_local std::string g_err;
-
+// records the message returned by fdm_last_error() on this thread and hands back `code` (shared with plan.hip)
 int fail(int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -27,6 +26,11 @@ int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
+}  // namespace fdm
+
+namespace {
+using fdm::fail;
+using fdm::g_err;
 
 int hip_fail(hipError_t e, const char* what) {
   return fail(FDM_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
@@ -413,8 +417,13 @@ int fdm_prog_instantiate(fdm_prog* p, void* stream) {
       p->lane_events.push_back(ev);
     }
   }
+  // Capture never executes anything, so it runs on a stream of the library's own: the caller's stream may be the legacy
+  // default stream (torch's current stream usually is), which cannot be captured.
+  hipStream_t cap = nullptr;
+  if (p->n_lanes == 1 && (e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+  struct CapGuard { hipStream_t s; ~CapGuard() { if (s) (void)hipStreamDestroy(s); } } guard{cap};
   for (int ln = 0; ln < p->n_lanes; ++ln) {
-    hipStream_t s = p->n_lanes > 1 ? p->lane_streams[ln] : (hipStream_t)stream;
+    hipStream_t s = p->n_lanes > 1 ? p->lane_streams[ln] : cap;
     e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
     hipError_t opErr = hipSuccess;
@@ -423,12 +432,18 @@ int fdm_prog_instantiate(fdm_prog* p, void* stream) {
       if (p->lane[i] == ln) { opErr = p->ops[i](s); ++n_ops; }
     hipGraph_t g = nullptr;
     e = hipStreamEndCapture(s, &g);
-    if (opErr != hipSuccess) return hip_fail(opErr, "prog_instantiate (launch during capture)");
-    if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
-    if (n_ops == 0) return fail(FDM_ERR_STATE, "prog_instantiate: lane %d has no ops", ln);
+    // a failure part-way leaves no half-built state behind: a later instantiate starts over, replay keeps failing loudly
+    auto cleanup = [&] {
+      for (auto x2 : p->execs) (void)hipGraphExecDestroy(x2);
+      for (auto g2 : p->graphs) (void)hipGraphDestroy(g2);
+      p->execs.clear(); p->graphs.clear();
+    };
+    if (opErr != hipSuccess) { if (g) (void)hipGraphDestroy(g); cleanup(); return hip_fail(opErr, "prog_instantiate (launch during capture)"); }
+    if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipStreamEndCapture"); }
+    if (n_ops == 0) { (void)hipGraphDestroy(g); cleanup(); return fail(FDM_ERR_STATE, "prog_instantiate: lane %d has no ops", ln); }
     hipGraphExec_t x = nullptr;
     e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
-    if (e != hipSuccess) return hip_fail(e, "hipGraphInstantiate");
+    if (e != hipSuccess) { (void)hipGraphDestroy(g); cleanup(); return hip_fail(e, "hipGraphInstantiate"); }
     p->graphs.push_back(g);
     p->execs.push_back(x);
   }

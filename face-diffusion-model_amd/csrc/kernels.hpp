@@ -5,6 +5,7 @@
 #include "../../include/fdm_hip.h"
 
 namespace fdm {
+int fail(int code, const char* fmt, ...);      // fdm_hip.hip: sets the thread's fdm_last_error() text, returns code
 hipError_t gemm_launch_f32(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_bf16(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_f16x3(const fdm_gemm_args& a, hipStream_t s);

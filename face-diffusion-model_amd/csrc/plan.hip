@@ -1,0 +1,1087 @@
+// Plan layer of libfdm_hip.so (include/fdm_hip.h, "Plan layer"): the FDM denoiser + diffusion scheduler of one model
+// behind plain C calls.  What the reference does in FDM.__init__ / FDM.forward (models/fdm_vocaset.py:9-91,
+// models/fdm_vqvae_mead.py:9-104, models/fdm.py:10-99) and GaussianDiffusion.p_sample_loop / ddim_sample
+// (video_diffusion_pytorch/diffusion_BIWI_encoder_decoder.py:649-710) is split here into
+//   commit   (once per model)   operand-kind weight copies, tau table, folded cross-attention time tables, LayerNorm folds
+//   prepare  (once per batch)   AF = audio_extract(features), per-layer tables C1_l, conditioning addend E0
+//   step program (per step)     recorded once through fdm_op_*, captured into a hipGraph, replayed with t from a device counter
+// All arithmetic runs in the library's own kernels (no torch, no vendor BLAS); host code only sequences launches.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/fdm_hip.h"
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+using fdm::fail;
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(FDM_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+#define FCK(x) do { int r_ = (x); if (r_ != FDM_OK) return r_; } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// one-time weight preparation kernels (plan commit)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void transpose_kernel(const float* in, float* out, int rows, int cols) {      // out[c][r] = in[r][c]
+  const long long n = (long long)rows * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i / rows), r = (int)(i % rows);
+    out[i] = in[(size_t)r * cols + c];
+  }
+}
+__global__ void scale_cols_kernel(const float* W, const float* gamma, float* out, long long n, int K) {   // out[j][k] = W[j][k] * gamma[k]
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = W[i] * gamma[i % K];
+}
+// out[j] = sum_k (float) Wt[j][k]: one wavefront per row, fixed order (lane-strided partial sums, then the DPP tree)
+__global__ __launch_bounds__(256) void rowsum_bf16_kernel(const fdm::bf16* W, float* out, int N, int K) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += (float)W[(size_t)row * K + k];
+  s = fdm::wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
+int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host tables
+// ---------------------------------------------------------------------------------------------------------------------
+void alibi_slopes(int n, std::vector<double>& out) {       // get_slopes, models/fdm_vocaset.py:96-106
+  auto p2 = [](int m, std::vector<double>& o) {
+    const double start = std::pow(2.0, -std::pow(2.0, -(std::log2((double)m) - 3.0)));
+    for (int i = 0; i < m; ++i) o.push_back(start * std::pow(start, (double)i));
+  };
+  const double l2 = std::log2((double)n);
+  if (l2 == std::floor(l2)) { p2(n, out); return; }
+  const int c = 1 << (int)std::floor(l2);
+  p2(c, out);
+  std::vector<double> more;
+  alibi_slopes(2 * c, more);
+  for (int i = 0; i < n - c; ++i) out.push_back(more[2 * i]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int fdm_schedule_host(int T, float* out) {
+  if (T <= 0 || !out) return fail(FDM_ERR_ARG, "schedule_host: bad argument");
+  // cosine_beta_schedule (:537-547) and the 12 buffers (:565-603), fp64 in the reference's expression order
+  const double s = 0.008;
+  std::vector<double> ac(T + 1), betas(T), alphas(T), acp(T), acprev(T);
+  for (int i = 0; i <= T; ++i) {
+    const double c = std::cos((((double)i / T) + s) / (1 + s) * M_PI * 0.5);
+    ac[i] = c * c;
+  }
+  const double a0 = ac[0];
+  for (int i = 0; i <= T; ++i) ac[i] = ac[i] / a0;
+  for (int i = 0; i < T; ++i) {
+    double b = 1 - (ac[i + 1] / ac[i]);
+    b = b < 0 ? 0 : (b > 0.9999 ? 0.9999 : b);
+    betas[i] = b;
+    alphas[i] = 1.0 - b;
+  }
+  double run = 1.0;
+  for (int i = 0; i < T; ++i) { acprev[i] = run; run = (i == 0) ? alphas[0] : run * alphas[i]; acp[i] = run; }
+  for (int i = 0; i < T; ++i) {
+    const double pv = betas[i] * (1.0 - acprev[i]) / (1.0 - acp[i]);
+    const double v[12] = {betas[i], acp[i], acprev[i], std::sqrt(acp[i]), std::sqrt(1.0 - acp[i]), std::log(1.0 - acp[i]),
+                          std::sqrt(1.0 / acp[i]), std::sqrt(1.0 / acp[i] - 1), pv, std::log(pv < 1e-20 ? 1e-20 : pv),
+                          betas[i] * std::sqrt(acprev[i]) / (1.0 - acp[i]), (1.0 - acprev[i]) * std::sqrt(alphas[i]) / (1.0 - acp[i])};
+    for (int k = 0; k < 12; ++k) out[(size_t)k * T + i] = (float)v[k];
+  }
+  return FDM_OK;
+}
+
+int fdm_ddim_schedule_host(int steps, int T, int* t, int* t_next, float* sqrt_an, float* c_n) {
+  if (steps <= 0 || T <= 0) return fail(FDM_ERR_ARG, "ddim_schedule_host: bad argument");
+  // times = linspace(-1, T-1, steps+1).astype(int32) reversed, zipped (:684-687); numpy: arange(num) * step + start, last = stop
+  std::vector<int> times(steps + 1);
+  const double start = -1.0, stop = (double)T - 1.0, step = (stop - start) / steps;
+  for (int i = 0; i <= steps; ++i) times[i] = (int)(i == steps ? stop : (double)i * step + start);
+  std::vector<float> buf;
+  if (sqrt_an || c_n) { buf.resize((size_t)12 * T); fdm_schedule_host(T, buf.data()); }
+  int n = 0;
+  for (int i = steps; i >= 1; --i) {
+    const int tc = times[i], tn = times[i - 1];
+    if (tn < 0) continue;                    // the dead last pair (:695-696)
+    if (t) t[n] = tc;
+    if (t_next) t_next[n] = tn;
+    if (sqrt_an || c_n) {
+      const float an = buf[(size_t)1 * T + tn];          // alphas_cumprod[t_next]; eta = 0 -> sigma = 0 (:699-708)
+      if (sqrt_an) sqrt_an[n] = std::sqrt(an);
+      if (c_n) c_n[n] = std::sqrt((1.f - an) - 0.f);
+    }
+    ++n;
+  }
+  return n;
+}
+
+int fdm_alibi_slopes_host(int n_head, float* out) {
+  if (n_head <= 0 || !out) return fail(FDM_ERR_ARG, "alibi_slopes_host: bad argument");
+  std::vector<double> v;
+  alibi_slopes(n_head, v);
+  for (int i = 0; i < n_head; ++i) out[i] = (float)v[i];
+  return FDM_OK;
+}
+
+int fdm_pe_table_host(int d, int periodic, int period, int rows, float* out) {
+  if (d <= 0 || d % 2 || rows <= 0 || !out || (periodic && period <= 0)) return fail(FDM_ERR_ARG, "pe_table_host: bad argument");
+  // pe[p, 2k] = sin(p w_k), pe[p, 2k+1] = cos(p w_k), w_k = exp(2k * (-ln 10000 / d)); periodic: p -> p mod period (:150-184).
+  // The reference evaluates these in fp32 torch ops; here each fp32 step is the correctly rounded value of the same function
+  // (<= 1 ulp from any fp32 libm); callers that need the reference buffer bit for bit pass "PE.pe" to fdm_plan_set_weights.
+  const float coef = (float)(-std::log(10000.0) / d);
+  for (int p = 0; p < rows; ++p) {
+    const float pos = (float)(periodic ? p % period : p);
+    for (int k = 0; k < d; k += 2) {
+      const float div = (float)std::exp((double)((float)k * coef));
+      const float arg = pos * div;
+      out[(size_t)p * d + k] = (float)std::sin((double)arg);
+      out[(size_t)p * d + k + 1] = (float)std::cos((double)arg);
+    }
+  }
+  return FDM_OK;
+}
+
+int fdm_model_preset(const char* name, fdm_model_desc* o) {
+  if (!name || !o) return fail(FDM_ERR_ARG, "model_preset: null argument");
+  const fdm_model_desc vocaset = {1024, 8, 8, 2048, 16, 64, 8, 0, 1024, 1, 1, 30, 1, 0, 600};
+  const fdm_model_desc mead = {512, 4, 8, 1024, 8, 64, 25, 7, 2048, 2, 0, 30, 1, 0, 600};
+  const fdm_model_desc biwi = {1024, 4, 8, 2048, 8, 128, 6, 0, 1536, 2, 0, 25, 0, 1, 600};
+  const std::string n(name);
+  if (n == "vocaset") *o = vocaset;
+  else if (n == "mead") *o = mead;
+  else if (n == "biwi") *o = biwi;
+  else if (n == "vocaset_tiny") { *o = vocaset; o->d = 256; o->n_head = 2; o->n_layers = 2; o->ffn = 512; o->c = 16; }
+  else if (n == "mead_tiny") { *o = mead; o->d = 256; o->n_head = 2; o->n_layers = 2; o->ffn = 512; o->c = 32; }
+  else return fail(FDM_ERR_ARG, "model_preset: unknown preset '%s'", name);
+  return FDM_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the plan
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Mat { void* p = nullptr; long long lo = 0; };       // operand-kind matrix: pointer + hi->lo plane distance (elements)
+struct Fold { Mat w; float* colsum = nullptr; float* bias = nullptr; const float* gamma = nullptr; const float* beta = nullptr; };
+struct Wt { float* p = nullptr; long long n = 0; };
+}  // namespace
+
+struct fdm_plan {
+  fdm_model_desc m{};
+  int dtype = FDM_F32, hd = 0;
+  std::vector<void*> allocs, ws_allocs;
+  std::map<std::string, Wt> w;               // fp32 weights / buffers by reference state-dict name (plan-owned copies)
+  bool committed = false;
+  // ---- per model
+  std::map<std::string, Mat> wt;             // operand-kind copies of the step's matrices
+  float* tau = nullptr;
+  std::vector<float*> TT;
+  std::vector<const float*> Wv, bv, Wo, bo;
+  bool fuse_ln3 = false;
+  std::map<int, Fold> fold;                  // layer l (1 .. n_layers-1) reads norm3 of layer l-1; -1 = latent decoder
+  float *slopes = nullptr, *pe = nullptr;
+  float *c1 = nullptr, *c2 = nullptr, *sigma = nullptr, *sra = nullptr, *srm1 = nullptr;
+  // ---- per shape (capacity cap*, current B, L, ...)
+  int capB = 0, capL = 0, capRep = 0;
+  int B = 0, L = 0, M = 0, rep = 1, R = 0, Lpad = 0, cfg = 0;
+  bool prepared = false;
+  float *h = nullptr, *h2 = nullptr, *x1 = nullptr, *x0 = nullptr, *x = nullptr, *x2 = nullptr, *stats = nullptr;
+  Mat xt, ht, h2t, x2t, ctx, u;
+  void *q = nullptr, *kp = nullptr, *vp = nullptr;
+  float *AF = nullptr, *t1 = nullptr, *sty = nullptr, *em = nullptr, *emu = nullptr, *zeros = nullptr, *E0 = nullptr;
+  std::vector<float*> C1;
+  int* step = nullptr;                       // [device step counter, t of the current step]
+  unsigned long long* seedbuf = nullptr;     // {Philox seed, global index of clip 0}: read by the scheduler at run time
+  int* tseq = nullptr; int tseq_cap = 0;
+  std::map<int, std::pair<int, float*>> ddim;   // ddim_steps -> (live pairs, device [san | cn])
+  std::map<int, std::vector<int>> ddim_t;
+  // ---- programs and tiles
+  std::map<std::string, fdm_prog*> progs;
+  std::vector<std::string> prog_order;
+  std::map<std::string, int> tiles;
+  std::map<std::string, std::map<std::string, int>> tile_cache;     // by shape key
+  std::map<std::string, long long> steps_seen;
+  std::map<std::string, std::vector<fdm_gemm_args>>* tune_rec = nullptr;
+  int tune_enabled = 1;
+  long long last_graph_launches = 0, launches_per_step = 0;
+};
+
+namespace {
+
+size_t esize(int dtype) { return dtype == FDM_F32 ? 4 : 2; }
+bool is_split(int dtype) { return dtype == FDM_F16X3 || dtype == FDM_BF16X3; }
+
+int dalloc(fdm_plan* P, void** out, size_t bytes, bool ws, bool zero = true) {
+  void* p = nullptr;
+  HIPCK(hipMalloc(&p, bytes ? bytes : 16));
+  if (zero) HIPCK(hipMemset(p, 0, bytes ? bytes : 16));
+  (ws ? P->ws_allocs : P->allocs).push_back(p);
+  *out = p;
+  return FDM_OK;
+}
+template <typename T> int dalloc_t(fdm_plan* P, T** out, size_t n, bool ws) { return dalloc(P, (void**)out, n * sizeof(T), ws); }
+// operand-kind matrix [rows, cols]: plain, or two consecutive planes for the split kinds
+int dalloc_mat(fdm_plan* P, Mat* out, size_t rows, size_t cols, bool ws) {
+  const size_t n = rows * cols;
+  out->lo = is_split(P->dtype) ? (long long)n : 0;
+  return dalloc(P, &out->p, n * esize(P->dtype) * (is_split(P->dtype) ? 2 : 1), ws);
+}
+Mat mat_rows(const fdm_plan* P, const Mat& m, size_t row0, size_t cols) {
+  Mat r = m;
+  r.p = (char*)m.p + row0 * cols * esize(P->dtype);
+  return r;
+}
+
+std::string shape_key(const fdm_plan* P) {
+  char b[64];
+  snprintf(b, sizeof(b), "%d,%d,%d,%d", P->R, P->M, P->L, P->rep);
+  return b;
+}
+
+int drop_programs(fdm_plan* P, void* stream) {
+  if (P->progs.empty()) return FDM_OK;
+  // graph execs / kernarg storage may still be referenced by queued replays: drain the stream they were launched on first
+  if (stream) HIPCK(hipStreamSynchronize((hipStream_t)stream));
+  else HIPCK(hipDeviceSynchronize());
+  for (auto& kv : P->progs) fdm_prog_destroy(kv.second);
+  P->progs.clear();
+  P->prog_order.clear();
+  return FDM_OK;
+}
+
+const Wt* weight(const fdm_plan* P, const std::string& name) {
+  auto it = P->w.find(name);
+  return it == P->w.end() ? nullptr : &it->second;
+}
+int need(const fdm_plan* P, const std::string& name, long long n, const float** out) {
+  const Wt* w = weight(P, name);
+  if (!w) return fail(FDM_ERR_STATE, "plan: missing weight %s", name.c_str());
+  if (w->n != n) return fail(FDM_ERR_SHAPE, "plan: weight %s has %lld elements, expected %lld", name.c_str(), w->n, n);
+  *out = w->p;
+  return FDM_OK;
+}
+
+// fp32 GEMM args with the defaults the op layer's callers use (dense row-major operands)
+fdm_gemm_args gemm_f32(const float* A, const float* W, int M, int N, int K) {
+  fdm_gemm_args a;
+  memset(&a, 0, sizeof(a));
+  a.A = A; a.lda = K; a.W = W; a.ldw = K; a.M = M; a.N = N; a.K = K; a.batch = 1; a.dtype = FDM_F32;
+  a.ldr = N; a.ldo_f32 = N; a.ldo_t = N; a.ln_eps = 1e-5f;
+  return a;
+}
+fdm_gemm_args gemm_op(const fdm_plan* P, const Mat& A, const Mat& W, int M, int N, int K) {
+  fdm_gemm_args a = gemm_f32((const float*)A.p, (const float*)W.p, M, N, K);
+  a.dtype = P->dtype; a.a_lo_off = A.lo; a.w_lo_off = W.lo;
+  return a;
+}
+void set_out_t(fdm_gemm_args& a, const Mat& o) { a.out_t = o.p; a.out_t_lo_off = o.lo; }
+
+int to_operand(fdm_plan* P, const float* src, long long n, Mat* out, void* stream) {
+  if (P->dtype == FDM_F32) { out->p = (void*)src; out->lo = 0; return FDM_OK; }
+  out->lo = is_split(P->dtype) ? n : 0;
+  FCK(dalloc(P, &out->p, (size_t)n * 2 * (is_split(P->dtype) ? 2 : 1), false, false));
+  return fdm_op_cast(src, out->p, n, P->dtype, stream);
+}
+
+int plan_gemm(fdm_plan* P, const char* label, fdm_gemm_args a, void* stream) {
+  if (P->tune_rec) (*P->tune_rec)[label].push_back(a);
+  auto it = P->tiles.find(label);
+  a.tile = it == P->tiles.end() ? 0 : it->second;
+  return fdm_op_gemm(&a, stream);
+}
+
+std::string lname(int l, const char* suffix) {
+  char b[96];
+  snprintf(b, sizeof(b), "transformer_decoder.layers.%d.%s", l, suffix);
+  return b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// commit: per-model tables
+// ---------------------------------------------------------------------------------------------------------------------
+int commit(fdm_plan* P, void* stream) {
+  if (P->committed) return FDM_OK;
+  const fdm_model_desc& m = P->m;
+  const int d = m.d;
+  hipStream_t s = (hipStream_t)stream;
+  FCK(drop_programs(P, stream));
+  const float* p = nullptr;
+  FCK(need(P, "audio_extract.0.weight", (long long)d * m.audio_in, &p));
+  FCK(need(P, "audio_extract.0.bias", d, &p));
+  FCK(need(P, "audio_extract.2.weight", (long long)d * d, &p));
+  FCK(need(P, "audio_extract.2.bias", d, &p));
+  FCK(need(P, "style_embedd.weight", (long long)d * m.n_style, &p));
+  FCK(need(P, "style_embedd.bias", d, &p));
+  if (m.n_emo) { FCK(need(P, "emotion_embedd.weight", (long long)d * m.n_emo, &p)); FCK(need(P, "emotion_embedd.bias", d, &p)); }
+  FCK(need(P, "latent_encoder.0.bias", d, &p));
+  FCK(need(P, "latent_decoder.bias", d, &p));
+  // operand-kind copies of the per-step matrices
+  std::vector<std::pair<std::string, long long>> mats = {{"latent_encoder.0.weight", (long long)d * d}, {"latent_decoder.weight", (long long)d * d}};
+  for (int l = 0; l < m.n_layers; ++l) {
+    mats.push_back({lname(l, "self_attn.in_proj_weight"), 3LL * d * d});
+    mats.push_back({lname(l, "self_attn.out_proj.weight"), (long long)d * d});
+    mats.push_back({lname(l, "linear1.weight"), (long long)m.ffn * d});
+    mats.push_back({lname(l, "linear2.weight"), (long long)d * m.ffn});
+    for (const char* b : {"self_attn.in_proj_bias", "self_attn.out_proj.bias", "linear1.bias", "linear2.bias", "norm1.weight", "norm1.bias",
+                          "norm2.weight", "norm2.bias", "norm3.weight", "norm3.bias"}) {
+      const long long nb = !strcmp(b, "self_attn.in_proj_bias") ? 3LL * d : (!strcmp(b, "linear1.bias") ? m.ffn : d);
+      FCK(need(P, lname(l, b), nb, &p));
+    }
+  }
+  for (auto& mt : mats) {
+    FCK(need(P, mt.first, mt.second, &p));
+    Mat o;
+    FCK(to_operand(P, p, mt.second, &o, stream));
+    P->wt[mt.first] = o;
+  }
+  // tau table [1000, d] = Mish(W_t^T + b_t): Linear(one_hot(t)) is a column gather (models/fdm_vocaset.py:71-72)
+  const float *Wt_ = nullptr, *bt = nullptr;
+  FCK(need(P, "time_embedd.0.weight", (long long)d * 1000, &Wt_));
+  FCK(need(P, "time_embedd.0.bias", d, &bt));
+  float* wtT = nullptr;
+  FCK(dalloc_t(P, &wtT, (size_t)1000 * d, false));
+  FCK(dalloc_t(P, &P->tau, (size_t)1000 * d, false));
+  hipLaunchKernelGGL(transpose_kernel, dim3(grid_for(1000LL * d)), dim3(256), 0, s, Wt_, wtT, d, 1000);
+  FCK(fdm_op_bias_act(wtT, bt, P->tau, 1000, d, FDM_ACT_MISH, stream));
+  // folded cross-attention time tables TT_l = (tau Wv_l^T) Wo_l^T: fp32 MFMA, one-time
+  float* tmp = nullptr;
+  FCK(dalloc_t(P, &tmp, (size_t)1000 * d, false));
+  P->TT.assign(m.n_layers, nullptr);
+  P->Wv.assign(m.n_layers, nullptr); P->bv = P->Wo = P->bo = P->Wv;
+  for (int l = 0; l < m.n_layers; ++l) {
+    const float *ipw = nullptr, *ipb = nullptr;
+    FCK(need(P, lname(l, "multihead_attn.in_proj_weight"), 3LL * d * d, &ipw));
+    FCK(need(P, lname(l, "multihead_attn.in_proj_bias"), 3LL * d, &ipb));
+    FCK(need(P, lname(l, "multihead_attn.out_proj.weight"), (long long)d * d, &P->Wo[l]));
+    FCK(need(P, lname(l, "multihead_attn.out_proj.bias"), d, &P->bo[l]));
+    P->Wv[l] = ipw + 2LL * d * d;
+    P->bv[l] = ipb + 2LL * d;
+    FCK(dalloc_t(P, &P->TT[l], (size_t)1000 * d, false));
+    fdm_gemm_args g = gemm_f32(P->tau, P->Wv[l], 1000, d, d);
+    g.out_f32 = tmp;
+    FCK(fdm_op_gemm(&g, stream));
+    g = gemm_f32(tmp, P->Wo[l], 1000, d, d);
+    g.out_f32 = P->TT[l];
+    FCK(fdm_op_gemm(&g, stream));
+  }
+  // bf16 step program: norm3 of layer l-1 folded into the QKV / out-proj GEMMs of layer l and into the latent decoder
+  //   LN(x) W^T + b = rstd (x W'^T - mu colsum(W')) + (W beta + b),  W' = W o gamma
+  const char* env = getenv("FDM_FUSE_LN3");
+  P->fuse_ln3 = P->dtype == FDM_BF16 && !(env && !strcmp(env, "0"));
+  if (P->fuse_ln3) {
+    auto make_fold = [&](const std::string& wname, const std::string& bname, int N, int l_prev, Fold* f) -> int {
+      const float *W = nullptr, *b = nullptr, *gam = nullptr, *bet = nullptr;
+      FCK(need(P, wname, (long long)N * d, &W));
+      FCK(need(P, bname, N, &b));
+      FCK(need(P, lname(l_prev, "norm3.weight"), d, &gam));
+      FCK(need(P, lname(l_prev, "norm3.bias"), d, &bet));
+      float* wg = nullptr;
+      FCK(dalloc_t(P, &wg, (size_t)N * d, false));
+      hipLaunchKernelGGL(scale_cols_kernel, dim3(grid_for((long long)N * d)), dim3(256), 0, s, W, gam, wg, (long long)N * d, d);
+      FCK(to_operand(P, wg, (long long)N * d, &f->w, stream));
+      FCK(dalloc_t(P, &f->colsum, (size_t)N, false));
+      hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, s, (const fdm::bf16*)f->w.p, f->colsum, N, d);
+      FCK(dalloc_t(P, &f->bias, (size_t)N, false));
+      FCK(fdm_op_small_linear(bet, W, b, f->bias, 1, d, N, FDM_ACT_NONE, stream));      // W beta + b
+      f->gamma = gam; f->beta = bet;
+      return FDM_OK;
+    };
+    for (int l = 1; l < m.n_layers; ++l)
+      FCK(make_fold(lname(l, "self_attn.in_proj_weight"), lname(l, "self_attn.in_proj_bias"), 3 * d, l - 1, &P->fold[l]));
+    FCK(make_fold("latent_decoder.weight", "latent_decoder.bias", d, m.n_layers - 1, &P->fold[-1]));
+  }
+  HIPCK(hipGetLastError());
+  // ALiBi slopes, positional table, schedule tables
+  std::vector<float> hs(m.n_head);
+  fdm_alibi_slopes_host(m.n_head, hs.data());
+  FCK(dalloc_t(P, &P->slopes, (size_t)m.n_head, false));
+  HIPCK(hipMemcpyAsync(P->slopes, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, s));
+  const int pe_rows = m.max_len + 30;
+  FCK(dalloc_t(P, &P->pe, (size_t)pe_rows * d, false));
+  if (const Wt* pw = weight(P, "PE.pe")) {           // the reference's registered buffer [1, rows, d]
+    if (pw->n < (long long)m.max_len * d) return fail(FDM_ERR_SHAPE, "plan: PE.pe has %lld elements, need >= %lld", pw->n, (long long)m.max_len * d);
+    const long long n = pw->n < (long long)pe_rows * d ? pw->n : (long long)pe_rows * d;
+    HIPCK(hipMemcpyAsync(P->pe, pw->p, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  } else {
+    std::vector<float> hp((size_t)pe_rows * d);
+    fdm_pe_table_host(d, m.pe_periodic, m.period, pe_rows, hp.data());
+    HIPCK(hipMemcpyAsync(P->pe, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, s));
+    HIPCK(hipStreamSynchronize(s));
+  }
+  std::vector<float> sb((size_t)12 * 1000);
+  fdm_schedule_host(1000, sb.data());
+  std::vector<float> sg(1000);
+  for (int i = 0; i < 1000; ++i) sg[i] = (float)std::exp((double)(0.5f * sb[9000 + i]));      // exp(0.5 logvar), p_sample :655
+  struct { const char* name; float** dst; const float* host; } tabs[] = {
+      {"sched.c1", &P->c1, &sb[10000]}, {"sched.c2", &P->c2, &sb[11000]}, {"sched.sigma", &P->sigma, sg.data()},
+      {"sched.sra", &P->sra, &sb[6000]}, {"sched.srm1", &P->srm1, &sb[7000]}};
+  for (auto& t : tabs) {
+    FCK(dalloc_t(P, t.dst, (size_t)1000, false));
+    if (const Wt* ow = weight(P, t.name)) {
+      if (ow->n != 1000) return fail(FDM_ERR_SHAPE, "plan: %s must have 1000 elements", t.name);
+      HIPCK(hipMemcpyAsync(*t.dst, ow->p, 4000, hipMemcpyDeviceToDevice, s));
+    } else {
+      HIPCK(hipMemcpyAsync(*t.dst, t.host, 4000, hipMemcpyHostToDevice, s));
+    }
+  }
+  HIPCK(hipStreamSynchronize(s));         // host staging vectors go out of scope
+  P->committed = true;
+  return FDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// workspaces
+// ---------------------------------------------------------------------------------------------------------------------
+int reserve(fdm_plan* P, int B, int L, int cfg) {
+  const int rep = cfg ? 2 : 1;
+  if (B <= P->capB && L <= P->capL && rep <= P->capRep) return FDM_OK;
+  B = B > P->capB ? B : P->capB; L = L > P->capL ? L : P->capL;
+  const int repc = rep > P->capRep ? rep : P->capRep;
+  FCK(drop_programs(P, nullptr));
+  for (void* p : P->ws_allocs) (void)hipFree(p);
+  P->ws_allocs.clear();
+  P->prepared = false;
+  const fdm_model_desc& m = P->m;
+  const size_t d = m.d, M = (size_t)B * L, R = M * repc;
+  const size_t Lpad = ((size_t)L + 31) / 32 * 32;
+  FCK(dalloc_t(P, &P->h, R * d, true)); FCK(dalloc_t(P, &P->h2, R * d, true)); FCK(dalloc_t(P, &P->x1, R * d, true));
+  FCK(dalloc_t(P, &P->x0, R * d, true)); FCK(dalloc_t(P, &P->x, M * d, true));
+  if (P->dtype != FDM_F32) {
+    FCK(dalloc_mat(P, &P->xt, M, d, true)); FCK(dalloc_mat(P, &P->ht, R, d, true)); FCK(dalloc_mat(P, &P->h2t, R, d, true));
+  } else {        // fp32 operands alias the fp32 residual-stream buffers
+    P->xt = Mat{P->x, 0}; P->ht = Mat{P->h, 0}; P->h2t = Mat{P->h2, 0};
+  }
+  if (P->dtype == FDM_BF16) {
+    FCK(dalloc_t(P, &P->x2, R * d, true)); FCK(dalloc_mat(P, &P->x2t, R, d, true)); FCK(dalloc_t(P, &P->stats, (d / 64) * R * 2, true));
+  }
+  // q: row-major queries; kp / vp: fragment-packed keys / values written by the QKV GEMM's epilogue (zeroed: pad keys must be
+  // finite).  Split modes: attention runs in fp32, ctx returns as a plane pair.
+  const size_t ea = (is_split(P->dtype) || P->dtype == FDM_F32) ? 4 : 2;
+  FCK(dalloc(P, &P->q, R * d * ea, true));
+  FCK(dalloc(P, &P->kp, (size_t)B * repc * Lpad * d * ea, true));
+  FCK(dalloc(P, &P->vp, (size_t)B * repc * Lpad * d * ea, true));
+  FCK(dalloc_mat(P, &P->ctx, R, d, true));
+  FCK(dalloc_mat(P, &P->u, R, m.ffn, true));
+  FCK(dalloc_t(P, &P->AF, M * d, true)); FCK(dalloc_t(P, &P->t1, M * d, true));
+  FCK(dalloc_t(P, &P->sty, (size_t)B * d, true)); FCK(dalloc_t(P, &P->em, (size_t)B * d, true)); FCK(dalloc_t(P, &P->emu, (size_t)B * d, true));
+  FCK(dalloc_t(P, &P->zeros, (size_t)B * (m.n_emo > 0 ? m.n_emo : 1), true));
+  FCK(dalloc_t(P, &P->E0, R * d, true));
+  P->C1.assign(m.n_layers, nullptr);
+  for (int l = 0; l < m.n_layers; ++l) FCK(dalloc_t(P, &P->C1[l], R * d, true));
+  FCK(dalloc_t(P, &P->step, (size_t)4, true));
+  FCK(dalloc_t(P, &P->seedbuf, (size_t)2, true));
+  if (!P->tseq) { P->tseq_cap = 1024; FCK(dalloc_t(P, &P->tseq, (size_t)P->tseq_cap, false)); }
+  P->capB = B; P->capL = L; P->capRep = repc;
+  return FDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the step program: one denoiser pass, ws.x (+ its operand copy) -> ws.x0, or -> x_{t-1} when the scheduler update is fused
+// ---------------------------------------------------------------------------------------------------------------------
+int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
+  const fdm_model_desc& m = P->m;
+  const int d = m.d, M = P->M, R = P->R, L = P->L;
+  const bool both = P->dtype != FDM_F32, split = is_split(P->dtype), fuse = P->fuse_ln3;
+  int* step = P->step; int* tcur = P->step + 1;
+  const float* none = nullptr; (void)none;
+  const float *b = nullptr;
+  for (int r = 0; r < P->rep; ++r) {
+    const size_t o = (size_t)r * M;
+    FCK(need(P, "latent_encoder.0.bias", d, &b));
+    fdm_gemm_args g = gemm_op(P, P->xt, P->wt["latent_encoder.0.weight"], M, d, d);
+    g.bias = b; g.act = m.latent_mish ? FDM_ACT_MISH : FDM_ACT_NONE;
+    g.resid = P->E0 + o * d; g.out_f32 = P->h + o * d;
+    if (both) set_out_t(g, mat_rows(P, P->ht, o, d));
+    if (r == 0) { g.incr_counter = step; g.incr_table = P->tseq; }      // first kernel of the step: counter += 1, tcur = tseq[counter]
+    FCK(plan_gemm(P, "enc", g, stream));
+  }
+  const int BB = P->B * P->rep;
+  const float eps = 1e-5f;
+  const int np = d / 64;
+  for (int l = 0; l < m.n_layers; ++l) {
+    const Fold* f = (fuse && l > 0) ? &P->fold[l] : nullptr;
+    fdm_gemm_args g;
+    if (!f) {
+      FCK(need(P, lname(l, "self_attn.in_proj_bias"), 3LL * d, &b));
+      g = gemm_op(P, P->ht, P->wt[lname(l, "self_attn.in_proj_weight")], R, 3 * d, d);
+      g.bias = b;
+    } else {          // layer input = LN3(x2) of the previous layer, never materialised
+      g = gemm_op(P, P->x2t, f->w, R, 3 * d, d);
+      g.bias = f->bias; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.ln_colsum = f->colsum;
+    }
+    if (split) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
+    else { g.out_t = P->q; g.ldo_t = d; }
+    g.out_kp = P->kp; g.kp_col0 = d; g.out_vp = P->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = P->Lpad; g.kv_hd = P->hd;
+    FCK(plan_gemm(P, f ? "qkv_ln" : "qkv", g, stream));
+    fdm_attn_args at;
+    memset(&at, 0, sizeof(at));
+    at.Q = P->q; at.ldq = d; at.Kp = P->kp; at.Vp = P->vp; at.Lpad = P->Lpad; at.O = P->ctx.p; at.ldo = d;
+    at.B = BB; at.H = m.n_head; at.L = L; at.hd = P->hd; at.dtype = split ? FDM_F32 : P->dtype;
+    at.scale = 1.0f / std::sqrt((float)P->hd); at.causal = 1; at.slopes = P->slopes; at.period = m.period;
+    if (split) { at.o_split = P->dtype; at.o_lo_off = P->ctx.lo; }
+    FCK(fdm_op_attention(&at, stream));
+    FCK(need(P, lname(l, "self_attn.out_proj.bias"), d, &b));
+    g = gemm_op(P, P->ctx, P->wt[lname(l, "self_attn.out_proj.weight")], R, d, d);
+    g.bias = b; g.out_f32 = P->x1;
+    if (!f) {
+      g.resid = P->h;
+      FCK(plan_gemm(P, "out", g, stream));
+    } else {
+      g.resid = P->x2; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.rln_gamma = f->gamma; g.rln_beta = f->beta;
+      FCK(plan_gemm(P, "out_ln", g, stream));
+    }
+    // norm1 and norm2 back to back in one kernel: h2 = LN2(LN1(x1) + C1_l + TT_l[t])
+    fdm_ln_args ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = P->x1; ln.M = R; ln.d = d; ln.add_mat = P->C1[l]; ln.add_tab = P->TT[l]; ln.tab_step = tcur; ln.eps = eps;
+    FCK(need(P, lname(l, "norm1.weight"), d, &ln.gamma)); FCK(need(P, lname(l, "norm1.bias"), d, &ln.beta));
+    FCK(need(P, lname(l, "norm2.weight"), d, &ln.gamma2)); FCK(need(P, lname(l, "norm2.bias"), d, &ln.beta2));
+    ln.y_f32 = P->h2; ln.dtype = P->dtype;
+    if (both) { ln.y_t = P->h2t.p; ln.y_t_lo_off = P->h2t.lo; }
+    FCK(fdm_op_layernorm(&ln, stream));
+    FCK(need(P, lname(l, "linear1.bias"), m.ffn, &b));
+    g = gemm_op(P, P->h2t, P->wt[lname(l, "linear1.weight")], R, m.ffn, d);
+    g.bias = b; g.act = FDM_ACT_RELU; set_out_t(g, P->u);
+    FCK(plan_gemm(P, "ffn1", g, stream));
+    FCK(need(P, lname(l, "linear2.bias"), d, &b));
+    g = gemm_op(P, P->u, P->wt[lname(l, "linear2.weight")], R, d, m.ffn);
+    g.bias = b; g.resid = P->h2;
+    if (fuse) {      // x2 = h2 + FFN(h2): fp32 + operand copy + per-row partial sums for the folded norm3
+      g.out_f32 = P->x2; set_out_t(g, P->x2t); g.stat_out = P->stats;
+      FCK(plan_gemm(P, "ffn2_stat", g, stream));
+    } else {
+      g.out_f32 = P->x1;
+      FCK(plan_gemm(P, "ffn2", g, stream));
+      memset(&ln, 0, sizeof(ln));
+      ln.x = P->x1; ln.M = R; ln.d = d; ln.eps = eps; ln.y_f32 = P->h; ln.dtype = P->dtype;
+      FCK(need(P, lname(l, "norm3.weight"), d, &ln.gamma)); FCK(need(P, lname(l, "norm3.bias"), d, &ln.beta));
+      if (both) { ln.y_t = P->ht.p; ln.y_t_lo_off = P->ht.lo; }
+      FCK(fdm_op_layernorm(&ln, stream));
+    }
+  }
+  fdm_gemm_args g;
+  if (fuse) {
+    const Fold& f = P->fold[-1];
+    g = gemm_op(P, P->x2t, f.w, R, d, d);
+    g.bias = f.bias; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.ln_colsum = f.colsum;
+  } else {
+    FCK(need(P, "latent_decoder.bias", d, &b));
+    g = gemm_op(P, P->ht, P->wt["latent_decoder.weight"], R, d, d);
+    g.bias = b;
+  }
+  if (sched) {       // x_{t-1} = update(x0_hat = this GEMM, x_t = ws.x) in the epilogue
+    g.resid = P->x; g.out_f32 = P->x;
+    if (both) set_out_t(g, P->xt);
+    g.sched_fuse = 1; g.sched = *sched;
+  } else {
+    g.out_f32 = P->x0;
+  }
+  return plan_gemm(P, fuse ? "dec_ln" : "dec", g, stream);
+}
+
+struct ProgSpec {
+  int kind;                  // 0 pass (denoiser only, + CFG mix), 1 DDPM, 2 DDIM
+  const float* noise = nullptr; float cfg_scale = 0.f;
+  const float* san = nullptr; const float* cn = nullptr;
+  int reps = 1;              // diffusion steps recorded back to back (one graph launch runs them all)
+};
+
+int get_program(fdm_plan* P, const ProgSpec& sp, void* stream, fdm_prog** out) {
+  char key[256];
+  snprintf(key, sizeof(key), "%d|%p|%a|%p|%d", sp.kind, (const void*)sp.noise, (double)sp.cfg_scale, (const void*)sp.san, sp.reps);
+  auto it = P->progs.find(key);
+  if (it != P->progs.end()) { *out = it->second; return FDM_OK; }
+  if (P->progs.size() >= 8) {          // programs are keyed by the pointers they captured (e.g. injected noise): cap the cache
+    HIPCK(hipStreamSynchronize((hipStream_t)stream));
+    const std::string victim = P->prog_order.front();
+    P->prog_order.erase(P->prog_order.begin());
+    fdm_prog_destroy(P->progs[victim]);
+    P->progs.erase(victim);
+  }
+  const int d = P->m.d, M = P->M;
+  const long long n = (long long)M * d;
+  fdm_prog* prog = nullptr;
+  FCK(fdm_prog_create(&prog));
+  int rc = fdm_prog_begin(prog);
+  const char* fs = getenv("FDM_FUSE_SCHED");
+  const bool fuse_sched = !P->cfg && sp.kind != 0 && !(fs && !strcmp(fs, "0"));
+  for (int rep = 0; rc == FDM_OK && rep < sp.reps; ++rep) {
+    fdm_sched_args sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.x0 = P->x0; sc.x0u = P->cfg ? P->x0 + n : nullptr; sc.cfg_scale = sp.cfg_scale;
+    sc.x = P->x; sc.x_out = P->x; sc.n = n; sc.tseq = P->tseq; sc.step = P->step; sc.advance = 0;
+    if (P->dtype != FDM_F32) { sc.x_out_t = P->xt.p; sc.out_dtype = P->dtype; sc.x_out_t_lo_off = P->xt.lo; }
+    if (sp.kind == 1) {
+      sc.mode = 0; sc.n_per_clip = (long long)P->L * d; sc.c1 = P->c1; sc.c2 = P->c2; sc.sigma = P->sigma;
+      sc.noise = sp.noise; sc.noise_stride = n; sc.seed_dev = P->seedbuf;
+    } else if (sp.kind == 2) {
+      sc.mode = 1; sc.sra = P->sra; sc.srm1 = P->srm1; sc.sqrt_an = sp.san; sc.c_n = sp.cn;
+    }
+    if (sp.kind != 0 && fuse_sched) {
+      // non-CFG samplers: the update runs in the latent decoder GEMM's epilogue (bit-identical, one launch less)
+      fdm_sched_args fs2 = sc;
+      fs2.x0 = fs2.x0u = fs2.x = nullptr; fs2.x_out = nullptr; fs2.x_out_t = nullptr;
+      rc = record_chain(P, &fs2, stream);
+      continue;
+    }
+    rc = record_chain(P, nullptr, stream);
+    if (rc != FDM_OK) break;
+    if (sp.kind != 0) {
+      rc = fdm_op_sched_step(&sc, stream);
+    } else if (P->cfg) {
+      sc.mode = 2; sc.x = nullptr; sc.x_out = P->x0; sc.x_out_t = nullptr;
+      rc = fdm_op_sched_step(&sc, stream);
+    }
+  }
+  const int rc2 = fdm_prog_end(prog);
+  if (rc != FDM_OK || rc2 != FDM_OK) { fdm_prog_destroy(prog); return rc != FDM_OK ? rc : rc2; }
+  if (sp.reps == 1) P->launches_per_step = fdm_prog_num_ops(prog);
+  P->progs[key] = prog;
+  P->prog_order.push_back(key);
+  *out = prog;
+  return FDM_OK;
+}
+
+int set_steps(fdm_plan* P, const int* ts, int n, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (n > P->tseq_cap) {
+    FCK(drop_programs(P, stream));
+    P->tseq_cap = n;
+    FCK(dalloc_t(P, &P->tseq, (size_t)n, false));
+  }
+  HIPCK(hipMemcpyAsync(P->tseq, ts, (size_t)n * 4, hipMemcpyHostToDevice, s));
+  const int init[2] = {-1, 0};       // the first GEMM of every step increments the counter before anything reads it
+  HIPCK(hipMemcpyAsync(P->step, init, 8, hipMemcpyHostToDevice, s));
+  HIPCK(hipStreamSynchronize(s));    // ts / init are caller / stack memory
+  return FDM_OK;
+}
+
+int load_x(fdm_plan* P, const float* x, void* stream) {
+  const long long n = (long long)P->M * P->m.d;
+  HIPCK(hipMemcpyAsync(P->x, x, (size_t)n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (P->dtype != FDM_F32) {
+    // (the plane distance of ws.xt is its capacity, not n: cast plane by plane through the op's contract lo = dst + n only
+    //  when they coincide; otherwise use the scheduler's store path with identity coefficients -- simpler: a strided cast)
+    if (!is_split(P->dtype) || P->xt.lo == n) return fdm_op_cast(P->x, P->xt.p, n, P->dtype, stream);
+    // capacity > current shape: run the mix-only scheduler mode (x_out = x0), which writes the operand copy with any plane distance
+    fdm_sched_args sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.mode = 2; sc.x0 = P->x; sc.x_out = P->x; sc.n = n; sc.x_out_t = P->xt.p; sc.out_dtype = P->dtype; sc.x_out_t_lo_off = P->xt.lo;
+    return fdm_op_sched_step(&sc, stream);
+  }
+  return FDM_OK;
+}
+
+int check_ready(const fdm_plan* P) {
+  if (!P) return fail(FDM_ERR_ARG, "plan: null plan");
+  if (!P->prepared) return fail(FDM_ERR_STATE, "plan: call fdm_audio_prepare first");
+  return FDM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plan-time tile tuning
+// ---------------------------------------------------------------------------------------------------------------------
+int time_prog(fdm_prog* prog, int warm, int reps, hipStream_t s, float* ms) {
+  hipEvent_t e0, e1;
+  HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+  int rc = fdm_prog_instantiate(prog, s);
+  if (rc == FDM_OK) rc = fdm_prog_replay(prog, warm, s);
+  if (rc == FDM_OK) {
+    (void)hipEventRecord(e0, s);
+    rc = fdm_prog_replay(prog, reps, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(ms, e0, e1);
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+
+int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
+  // Time the candidate output tiles of every GEMM call site of the step at this plan's shapes and keep the fastest.  Each
+  // candidate runs the call site's per-layer instances (distinct weights, so they come from beyond L2 as they do inside the
+  // step) as a replayed graph; cached per shape, and lazily only for shapes the plan keeps being used at (after 2000 steps;
+  // n_steps < 0 forces).  Every tile accumulates k in the same order, so the choice changes speed only, never results.
+  const std::string key = shape_key(P);
+  const char* env = getenv("FDM_TUNE");
+  if (!P->tune_enabled || (env && !strcmp(env, "0")) || P->tile_cache.count(key)) return FDM_OK;
+  if (n_steps >= 0) {
+    long long& seen = P->steps_seen[key];
+    const long long before = seen;
+    seen += n_steps;
+    if (before < 2000) return FDM_OK;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  FCK(drop_programs(P, stream));
+  P->tiles.clear();
+  std::map<std::string, std::vector<fdm_gemm_args>> calls;
+  {      // dry recording of one pass: captures each call site's arguments, runs nothing
+    fdm_prog* dry = nullptr;
+    FCK(fdm_prog_create(&dry));
+    int rc = fdm_prog_begin(dry);
+    P->tune_rec = &calls;
+    if (rc == FDM_OK) rc = record_chain(P, nullptr, stream);
+    P->tune_rec = nullptr;
+    (void)fdm_prog_end(dry);
+    fdm_prog_destroy(dry);
+    FCK(rc);
+  }
+  auto timed = [&](const std::vector<fdm_gemm_args>& inst, int tile, float* best) -> int {
+    *best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      fdm_prog* prog = nullptr;
+      FCK(fdm_prog_create(&prog));
+      int rc = fdm_prog_begin(prog);
+      for (size_t i = 0; rc == FDM_OK && i < inst.size(); ++i) { fdm_gemm_args a = inst[i]; a.tile = tile; a.incr_counter = nullptr; a.incr_table = nullptr; rc = fdm_op_gemm(&a, stream); }
+      (void)fdm_prog_end(prog);
+      float ms = 0.f;
+      if (rc == FDM_OK) rc = time_prog(prog, 2, 5, s, &ms);
+      HIPCK(hipStreamSynchronize(s));
+      fdm_prog_destroy(prog);
+      FCK(rc);
+      if (ms < *best) *best = ms;
+    }
+    return FDM_OK;
+  };
+  std::vector<int> cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64, FDM_TILE_128x64_S3,
+                            FDM_TILE_128x128, FDM_TILE_96x128};
+  if (is_split(P->dtype)) cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64_S3, FDM_TILE_128x128};
+  else if (P->R >= 1024) cands.push_back(FDM_TILE_256x128);
+  std::map<std::string, int> tuned, runner_up;
+  for (auto& kv : calls) {
+    std::vector<fdm_gemm_args> inst = kv.second;
+    while (inst.size() < 4) { auto c = inst; inst.insert(inst.end(), c.begin(), c.end()); }
+    float base = 0.f;
+    FCK(timed(inst, 0, &base));
+    std::vector<std::pair<float, int>> cand = {{base * 0.97f, 0}};          // switch only for a > 3 % gain over the heuristic
+    for (int tile : cands) { float t = 0.f; FCK(timed(inst, tile, &t)); cand.push_back({t, tile}); }
+    std::sort(cand.begin(), cand.end());
+    tuned[kv.first] = cand[0].second;
+    if (cand.size() > 1 && cand[1].first < cand[0].first * 1.05f) runner_up[kv.first] = cand[1].second;   // settled inside the chain below
+  }
+  // the isolated timings can mislead (cache state inside the step differs): keep the tuned set only if one whole denoiser
+  // pass is faster with it than with the heuristic
+  auto chain_time = [&](const std::map<std::string, int>& tiles, float* best) -> int {
+    *best = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {
+      P->tiles = tiles;
+      const int init[2] = {-1, 0};
+      HIPCK(hipMemcpyAsync(P->step, init, 8, hipMemcpyHostToDevice, s));
+      fdm_prog* prog = nullptr;
+      FCK(fdm_prog_create(&prog));
+      int rc = fdm_prog_begin(prog);
+      if (rc == FDM_OK) rc = record_chain(P, nullptr, stream);
+      (void)fdm_prog_end(prog);
+      float ms = 0.f;
+      if (rc == FDM_OK) rc = time_prog(prog, 2, 4, s, &ms);
+      HIPCK(hipStreamSynchronize(s));
+      fdm_prog_destroy(prog);
+      FCK(rc);
+      if (ms < *best) *best = ms;
+    }
+    return FDM_OK;
+  };
+  bool any = !runner_up.empty();
+  for (auto& kv : tuned) any = any || kv.second != 0;
+  std::map<std::string, int> keep;
+  if (any) {
+    float t_h = 0.f, t_t = 0.f;
+    FCK(chain_time({}, &t_h));
+    FCK(chain_time(tuned, &t_t));
+    for (auto& kv : runner_up) {            // close calls: try the runner-up in place, keep what the chain prefers
+      std::map<std::string, int> trial = tuned;
+      trial[kv.first] = kv.second;
+      float t_a = 0.f;
+      FCK(chain_time(trial, &t_a));
+      if (t_a < 0.997f * t_t) { tuned = trial; t_t = t_a; }
+    }
+    if (t_t < 0.995f * t_h) keep = tuned;
+    if (getenv("FDM_TUNE_VERBOSE")) {
+      std::string desc;
+      for (auto& kv : tuned) desc += kv.first + "=" + std::to_string(kv.second) + " ";
+      fprintf(stderr, "[fdm tune] rows=%d candidates: %s chain %.3f -> %.3f ms: %s\n", P->R, desc.c_str(), t_h / 4, t_t / 4, keep.empty() ? "rejected" : "kept");
+    }
+  }
+  P->tiles = keep;
+  if (const char* ov = getenv("FDM_TILE_OVERRIDE")) {       // experiments: "qkv_ln=5,ffn1=3" forces call sites after the tuning
+    std::string sov(ov);
+    size_t pos = 0;
+    while (pos < sov.size()) {
+      const size_t comma = sov.find(',', pos), eq = sov.find('=', pos);
+      const size_t end = comma == std::string::npos ? sov.size() : comma;
+      if (eq != std::string::npos && eq < end) P->tiles[sov.substr(pos, eq - pos)] = atoi(sov.substr(eq + 1, end - eq - 1).c_str());
+      pos = end + 1;
+    }
+  }
+  P->tile_cache[key] = P->tiles;
+  return FDM_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+int fdm_plan_create(const fdm_model_desc* desc, int B, int L, int cfg, int dtype, fdm_plan** out) {
+  if (!desc || !out) return fail(FDM_ERR_ARG, "plan_create: null argument");
+  if (dtype < FDM_F32 || dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "plan_create: bad dtype %d", dtype);
+  const fdm_model_desc& m = *desc;
+  if (m.d <= 0 || m.n_head <= 0 || m.d % m.n_head || m.n_layers <= 0 || m.ffn <= 0 || m.G * m.c != m.d || m.pair <= 0 || m.max_len <= 0)
+    return fail(FDM_ERR_SHAPE, "plan_create: inconsistent model geometry (d %d, heads %d, G*c %d)", m.d, m.n_head, m.G * m.c);
+  const int hd = m.d / m.n_head;
+  if (hd != 64 && hd != 128 && hd != 256) return fail(FDM_ERR_SHAPE, "plan_create: head_dim %d unsupported (64, 128, 256)", hd);
+  if (m.d != 256 && m.d != 512 && m.d != 768 && m.d != 1024) return fail(FDM_ERR_SHAPE, "plan_create: feature_dim %d unsupported (256, 512, 768, 1024)", m.d);
+  if (B < 1 || L < 1 || L > m.max_len) return fail(FDM_ERR_SHAPE, "plan_create: B=%d, L=%d outside [1, .] x [1, %d] (models/fdm_vocaset.py:44)", B, L, m.max_len);
+  if (!fdm_device_ok()) return fail(FDM_ERR_STATE, "plan_create: no gfx950 device visible (there is no CPU fallback)");
+  fdm_plan* P = new (std::nothrow) fdm_plan();
+  if (!P) return fail(FDM_ERR_STATE, "plan_create: out of memory");
+  P->m = m; P->dtype = dtype; P->hd = hd;
+  const int rc = reserve(P, B, L, cfg);
+  if (rc != FDM_OK) { fdm_plan_destroy(P); return rc; }
+  *out = P;
+  return FDM_OK;
+}
+
+int fdm_plan_reserve(fdm_plan* P, int B, int L, int cfg) {
+  if (!P) return fail(FDM_ERR_ARG, "plan_reserve: null plan");
+  if (B < 1 || L < 1 || L > P->m.max_len) return fail(FDM_ERR_SHAPE, "plan_reserve: B=%d, L=%d outside [1, .] x [1, %d]", B, L, P->m.max_len);
+  return reserve(P, B, L, cfg);
+}
+
+int fdm_plan_destroy(fdm_plan* P) {
+  if (!P) return FDM_OK;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : P->progs) fdm_prog_destroy(kv.second);
+  for (void* p : P->ws_allocs) (void)hipFree(p);
+  for (void* p : P->allocs) (void)hipFree(p);
+  delete P;
+  return FDM_OK;
+}
+
+int fdm_plan_set_weights(fdm_plan* P, const char* name, const float* ptr, long long n, void* stream) {
+  if (!P || !name || !ptr || n <= 0) return fail(FDM_ERR_ARG, "plan_set_weights: bad argument");
+  Wt& w = P->w[name];
+  if (w.n != n) {
+    w.n = n;
+    FCK(dalloc_t(P, &w.p, (size_t)n, false));
+  }
+  HIPCK(hipMemcpyAsync(w.p, ptr, (size_t)n * 4, hipMemcpyDefault, (hipStream_t)stream));
+  if (P->committed) {      // a weight changed under the derived tables: rebuild them at the next prepare
+    P->committed = false; P->prepared = false;
+    P->wt.clear(); P->fold.clear();
+  }
+  return FDM_OK;
+}
+
+int fdm_plan_commit(fdm_plan* P, void* stream) {
+  if (!P) return fail(FDM_ERR_ARG, "plan_commit: null plan");
+  return commit(P, stream);
+}
+
+int fdm_audio_prepare(fdm_plan* P, const float* hub, int B, int N, int fw, const float* style, const float* emo, int L, int cfg, void* stream) {
+  if (!P || !hub || !style) return fail(FDM_ERR_ARG, "audio_prepare: null argument");
+  const fdm_model_desc& m = P->m;
+  if (B < 1 || N < 1 || fw < 1) return fail(FDM_ERR_SHAPE, "audio_prepare: bad feature shape [%d, %d, %d]", B, N, fw);
+  if (m.pair * fw != m.audio_in) return fail(FDM_ERR_SHAPE, "audio_prepare: audio feature width %d x pair %d != audio_extract input %d", fw, m.pair, m.audio_in);
+  if (L < 1 || L > N / m.pair || L > m.max_len) return fail(FDM_ERR_SHAPE, "audio_prepare: latent frames L=%d outside [1, min(%d, %d)] (models/fdm_vocaset.py:44,64-66)", L, N / m.pair, m.max_len);
+  if (m.n_emo && !emo) return fail(FDM_ERR_ARG, "audio_prepare: this model needs an emotion one-hot");
+  FCK(commit(P, stream));
+  FCK(reserve(P, B, L, cfg));
+  // recorded programs hold the workspace pointers and the shape, not the clip tables' contents: a new batch of the same
+  // shape (serving) keeps them and their instantiated graphs
+  if (!(P->prepared && P->B == B && P->L == L && P->cfg == (cfg ? 1 : 0))) FCK(drop_programs(P, stream));
+  hipStream_t s = (hipStream_t)stream;
+  const int d = m.d, M = B * L, rep = cfg ? 2 : 1;
+  P->B = B; P->L = L; P->M = M; P->rep = rep; P->R = M * rep; P->cfg = cfg ? 1 : 0; P->Lpad = (L + 31) / 32 * 32;
+  // pad keys of the packed K / V buffers must be finite: the layout depends on (L, Lpad), so clear them per shape
+  const size_t ea = P->dtype == FDM_BF16 ? 2 : 4;
+  HIPCK(hipMemsetAsync(P->kp, 0, (size_t)B * rep * P->Lpad * d * ea, s));
+  HIPCK(hipMemsetAsync(P->vp, 0, (size_t)B * rep * P->Lpad * d * ea, s));
+  const float *w0 = nullptr, *b0 = nullptr, *w2 = nullptr, *b2 = nullptr;
+  FCK(need(P, "audio_extract.0.weight", (long long)d * m.audio_in, &w0)); FCK(need(P, "audio_extract.0.bias", d, &b0));
+  FCK(need(P, "audio_extract.2.weight", (long long)d * d, &w2)); FCK(need(P, "audio_extract.2.bias", d, &b2));
+  // audio rows: `pair` consecutive encoder frames per latent frame (models/fdm_vqvae_mead.py:73), cropped to L (:64-66);
+  // the rows of a clip are contiguous in hub, so each clip's GEMM reads them in place (fp32: once per clip, parity)
+  for (int b = 0; b < B; ++b) {
+    fdm_gemm_args g = gemm_f32(hub + (size_t)b * N * fw, w0, L, d, m.audio_in);
+    g.bias = b0; g.act = FDM_ACT_MISH; g.out_f32 = P->t1 + (size_t)b * L * d;
+    FCK(fdm_op_gemm(&g, stream));
+  }
+  fdm_gemm_args g = gemm_f32(P->t1, w2, M, d, d);
+  g.bias = b2; g.out_f32 = P->AF;
+  FCK(fdm_op_gemm(&g, stream));
+  // folded cross-attention tables C1_l = Wo_l (Wv_l AF + bv_l) + bo_l, layout [rep][M, d]
+  for (int l = 0; l < m.n_layers; ++l) {
+    g = gemm_f32(P->AF, P->Wv[l], M, d, d);
+    g.bias = P->bv[l]; g.out_f32 = P->t1;
+    FCK(fdm_op_gemm(&g, stream));
+    g = gemm_f32(P->t1, P->Wo[l], M, d, d);
+    g.bias = P->bo[l]; g.out_f32 = P->C1[l];
+    FCK(fdm_op_gemm(&g, stream));
+    if (rep == 2) HIPCK(hipMemcpyAsync(P->C1[l] + (size_t)M * d, P->C1[l], (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
+  }
+  // conditioning addend E0 = PE[l] + style[b] (+ emotion[b]) (:75-84)
+  const float *sw = nullptr, *sbias = nullptr;
+  FCK(need(P, "style_embedd.weight", (long long)d * m.n_style, &sw)); FCK(need(P, "style_embedd.bias", d, &sbias));
+  FCK(fdm_op_small_linear(style, sw, sbias, P->sty, B, m.n_style, d, m.style_mish ? FDM_ACT_MISH : FDM_ACT_NONE, stream));
+  const float *ew = nullptr, *eb = nullptr;
+  if (m.n_emo) {
+    FCK(need(P, "emotion_embedd.weight", (long long)d * m.n_emo, &ew)); FCK(need(P, "emotion_embedd.bias", d, &eb));
+    FCK(fdm_op_small_linear(emo, ew, eb, P->em, B, m.n_emo, d, FDM_ACT_NONE, stream));
+    // null condition = zeros_like(emotion one-hot) (models/fdm_vqvae_mead.py:56-57) -> bias only
+    if (cfg) FCK(fdm_op_small_linear(P->zeros, ew, eb, P->emu, B, m.n_emo, d, FDM_ACT_NONE, stream));
+  }
+  for (int r = 0; r < rep; ++r) {
+    const float* e = m.n_emo ? (r == 1 ? P->emu : P->em) : nullptr;
+    FCK(fdm_op_add_rows(P->pe, 1, L, P->sty, L, B, e, L, B, P->E0 + (size_t)r * M * d, M, d, stream));
+  }
+  P->prepared = true;
+  auto it = P->tile_cache.find(shape_key(P));
+  P->tiles = it == P->tile_cache.end() ? std::map<std::string, int>() : it->second;
+  return FDM_OK;
+}
+
+int fdm_denoise_step(fdm_plan* P, const float* x_t, int t, float cfg_scale, float* x0_hat, float* x0_uncond, void* stream) {
+  FCK(check_ready(P));
+  if (!x_t || !x0_hat || t < 0 || t >= 1000) return fail(FDM_ERR_ARG, "denoise_step: bad argument (t = %d)", t);
+  FCK(load_x(P, x_t, stream));
+  FCK(set_steps(P, &t, 1, stream));
+  ProgSpec sp; sp.kind = 0; sp.cfg_scale = cfg_scale;
+  fdm_prog* prog = nullptr;
+  FCK(get_program(P, sp, stream, &prog));
+  FCK(fdm_prog_run(prog, stream));
+  const size_t nb = (size_t)P->M * P->m.d * 4;
+  HIPCK(hipMemcpyAsync(x0_hat, P->x0, nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (x0_uncond && P->cfg) HIPCK(hipMemcpyAsync(x0_uncond, P->x0 + (size_t)P->M * P->m.d, nb, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return FDM_OK;
+}
+
+int fdm_sample_graph(fdm_plan* P, const fdm_sample_args* a, void* stream) {
+  FCK(check_ready(P));
+  if (!a || !a->x_T || !a->out) return fail(FDM_ERR_ARG, "sample_graph: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<int> ts;
+  ProgSpec sp;
+  sp.cfg_scale = a->cfg_scale;
+  if (a->kind == 0) {
+    if (!a->t_list || a->n_steps <= 0) return fail(FDM_ERR_ARG, "sample_graph: DDPM needs t_list / n_steps");
+    for (int i = 0; i < a->n_steps; ++i) {
+      if (a->t_list[i] < 0 || a->t_list[i] >= 1000) return fail(FDM_ERR_ARG, "sample_graph: timestep %d outside [0, 1000)", a->t_list[i]);
+      ts.push_back(a->t_list[i]);
+    }
+    sp.kind = 1; sp.noise = a->noise;
+    const unsigned long long sd[2] = {a->seed, (unsigned long long)(unsigned)a->clip0};     // set_steps() below drains the copy
+    HIPCK(hipMemcpyAsync(P->seedbuf, sd, 16, hipMemcpyHostToDevice, s));
+  } else if (a->kind == 1) {
+    if (a->ddim_steps <= 0) return fail(FDM_ERR_ARG, "sample_graph: DDIM needs ddim_steps");
+    if (!P->ddim.count(a->ddim_steps)) {
+      std::vector<int> t(a->ddim_steps), tn(a->ddim_steps);
+      std::vector<float> tab(2 * (size_t)a->ddim_steps);
+      const int n = fdm_ddim_schedule_host(a->ddim_steps, 1000, t.data(), tn.data(), tab.data(), tab.data() + a->ddim_steps);
+      if (n < 0) return n;
+      float* dv = nullptr;
+      FCK(dalloc_t(P, &dv, 2 * (size_t)a->ddim_steps, false));
+      HIPCK(hipMemcpyAsync(dv, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, s));
+      HIPCK(hipStreamSynchronize(s));
+      t.resize(n);
+      P->ddim[a->ddim_steps] = {n, dv};
+      P->ddim_t[a->ddim_steps] = t;
+    }
+    ts = P->ddim_t[a->ddim_steps];
+    sp.kind = 2; sp.san = P->ddim[a->ddim_steps].second; sp.cn = sp.san + a->ddim_steps;
+  } else {
+    return fail(FDM_ERR_ARG, "sample_graph: kind %d (0 = DDPM, 1 = DDIM)", a->kind);
+  }
+  const int n_steps = (int)ts.size();
+  const size_t nb = (size_t)P->M * P->m.d * 4;
+  P->last_graph_launches = 0;
+  if (n_steps == 0) {        // e.g. ddim_steps = 1: only the dead pair
+    if (a->out != a->x_T) HIPCK(hipMemcpyAsync(a->out, a->x_T, nb, hipMemcpyDeviceToDevice, s));
+    return FDM_OK;
+  }
+  FCK(tune_tiles(P, n_steps, stream));
+  FCK(load_x(P, a->x_T, stream));
+  FCK(set_steps(P, ts.data(), n_steps, stream));
+  fdm_prog* p1 = nullptr;
+  FCK(get_program(P, sp, stream, &p1));
+  if (a->record || a->eager) {
+    for (int i = 0; i < n_steps; ++i) {
+      if (a->eager) { FCK(fdm_prog_run(p1, stream)); }
+      else { FCK(fdm_prog_instantiate(p1, stream)); FCK(fdm_prog_replay(p1, 1, stream)); ++P->last_graph_launches; }
+      if (a->record) HIPCK(hipMemcpyAsync(a->record + (size_t)i * P->M * P->m.d, P->x, nb, hipMemcpyDeviceToDevice, s));
+    }
+  } else {
+    static const int env_k = [] { const char* e = getenv("FDM_GRAPH_STEPS"); return e ? atoi(e) : 0; }();
+    int K = a->graph_steps > 0 ? a->graph_steps : (env_k > 0 ? env_k : 10);
+    if (K > n_steps) K = n_steps;
+    int left = n_steps;
+    if (K > 1) {
+      ProgSpec spk = sp; spk.reps = K;
+      fdm_prog* pk = nullptr;
+      FCK(get_program(P, spk, stream, &pk));
+      FCK(fdm_prog_instantiate(pk, stream));
+      FCK(fdm_prog_replay(pk, left / K, stream));
+      P->last_graph_launches += left / K;
+      left %= K;
+    }
+    if (left) {
+      FCK(fdm_prog_instantiate(p1, stream));
+      FCK(fdm_prog_replay(p1, left, stream));
+      P->last_graph_launches += left;
+    }
+  }
+  HIPCK(hipMemcpyAsync(a->out, P->x, nb, hipMemcpyDeviceToDevice, s));
+  return FDM_OK;
+}
+
+int fdm_plan_tune(fdm_plan* P, void* stream) {
+  FCK(check_ready(P));
+  return tune_tiles(P, -1, stream);
+}
+
+int fdm_plan_get(fdm_plan* P, const char* key, long long* out) {
+  if (!P || !key || !out) return fail(FDM_ERR_ARG, "plan_get: null argument");
+  const std::string k(key);
+  if (k == "launches_per_step") *out = P->launches_per_step;
+  else if (k == "graph_launches") *out = P->last_graph_launches;
+  else if (k == "fuse_ln3") *out = P->fuse_ln3;
+  else if (k == "rows") *out = P->R;
+  else if (k == "tuned") *out = P->tile_cache.count(shape_key(P)) ? 1 : 0;
+  else if (k.rfind("tile.", 0) == 0) { auto it = P->tiles.find(k.substr(5)); *out = it == P->tiles.end() ? 0 : it->second; }
+  else return fail(FDM_ERR_ARG, "plan_get: unknown key '%s'", key);
+  return FDM_OK;
+}
+
+int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
+  if (!P || !key) return fail(FDM_ERR_ARG, "plan_set: null argument");
+  const std::string k(key);
+  if (k == "tune") { P->tune_enabled = value != 0; return FDM_OK; }
+  if (k == "untune") {      // forget the tuned tiles of every shape (tests)
+    P->tile_cache.clear(); P->steps_seen.clear(); P->tiles.clear();
+    return drop_programs(P, nullptr);
+  }
+  if (k.rfind("tile.", 0) == 0) {
+    if (value < 0 || value > FDM_TILE_32x64_S3) return fail(FDM_ERR_ARG, "plan_set: unknown tile %lld", value);
+    P->tiles[k.substr(5)] = (int)value;
+    P->tile_cache[shape_key(P)] = P->tiles;      // an explicit choice counts as tuned: sampling calls keep it
+    return drop_programs(P, nullptr);
+  }
+  return fail(FDM_ERR_ARG, "plan_set: unknown key '%s'", key);
+}
+
+}  // extern "C"

@@ -45,13 +45,15 @@ __device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigne
 // Per-step scalars of the update (k = step index, t = tseq[k]) and the update of 4 consecutive latent elements starting at
 // flat element e of the x buffer.  Shared by sched_kernel and by the GEMM epilogue's fused form (fdm_gemm_args.sched_fuse),
 // so both produce the same bits.
-struct SchedCoef { int k, t; float c1, c2, sg, sra, srm1, san, cn; };
+struct SchedCoef { int k, t; float c1, c2, sg, sra, srm1, san, cn; unsigned long long seed; int clip0; };
 __device__ __forceinline__ SchedCoef sched_coef_load(const fdm_sched_args& p) {
   SchedCoef c;
   c.k = p.step ? *(volatile const int*)p.step : 0;
   c.t = p.tseq ? p.tseq[c.k] : c.k;
   c.c1 = c.c2 = c.sg = c.sra = c.san = c.cn = 0.f;
   c.srm1 = 1.f;
+  c.seed = p.seed_dev ? p.seed_dev[0] : p.seed;
+  c.clip0 = p.seed_dev ? (int)p.seed_dev[1] : p.clip0;
   if (p.mode == 0) { c.c1 = p.c1[c.t]; c.c2 = p.c2[c.t]; c.sg = p.sigma[c.t]; }
   if (p.mode == 1) { c.sra = p.sra[c.t]; c.srm1 = p.srm1[c.t]; c.san = p.sqrt_an[c.k]; c.cn = p.c_n[c.k]; }
   return c;
@@ -67,8 +69,8 @@ __device__ __forceinline__ f32x4 sched_update4(const fdm_sched_args& p, const Sc
         z = *(const f32x4*)(p.noise + (size_t)c.k * (p.noise_stride > 0 ? p.noise_stride : p.n) + e);
       } else {
         const int clip = (int)(e / p.n_per_clip);
-        z = philox_normal4(p.seed, (unsigned)((e - (long long)clip * p.n_per_clip) >> 2), (unsigned)c.k,
-                           (unsigned)(p.clip0 + clip));
+        z = philox_normal4(c.seed, (unsigned)((e - (long long)clip * p.n_per_clip) >> 2), (unsigned)c.k,
+                           (unsigned)(c.clip0 + clip));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(o[j], __fmul_rn(c.sg, z[j]));

@@ -19,7 +19,7 @@ class SchedArgs(C.Structure):
                 ("c1", vp), ("c2", vp), ("sigma", vp), ("sra", vp), ("srm1", vp),
                 ("sqrt_an", vp), ("c_n", vp), ("noise", vp), ("noise_stride", ll), ("x_out_t", vp), ("out_dtype", ci), ("arrive", vp),
                 ("seed", C.c_ulonglong), ("clip0", ci),
-                ("mode", ci), ("x_out_t_lo_off", ll)]
+                ("mode", ci), ("x_out_t_lo_off", ll), ("seed_dev", vp)]
 
 
 class GemmArgs(C.Structure):
@@ -39,6 +39,16 @@ class GemmArgs(C.Structure):
 
 
 TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, ci) for n in ("d", "n_head", "n_layers", "ffn", "G", "c", "n_style", "n_emo", "audio_in", "pair",
+                                  "pe_periodic", "period", "latent_mish", "style_mish", "max_len")]
+
+
+class SampleArgs(C.Structure):
+    _fields_ = [("kind", ci), ("x_T", vp), ("out", vp), ("t_list", vp), ("n_steps", ci), ("ddim_steps", ci), ("noise", vp),
+                ("seed", C.c_ulonglong), ("clip0", ci), ("cfg_scale", cf), ("eager", ci), ("record", vp), ("graph_steps", ci)]
 
 
 class AttnArgs(C.Structure):
@@ -88,6 +98,22 @@ SYMBOLS = {
     "fdm_prog_num_ops": (ci, [vp]),
     "fdm_prog_set_lane": (ci, [vp, ci]),
     "fdm_prog_run_lanes": (ci, [vp, ci, vp]),
+    "fdm_model_preset": (ci, [C.c_char_p, C.POINTER(ModelDesc)]),
+    "fdm_plan_create": (ci, [C.POINTER(ModelDesc), ci, ci, ci, ci, C.POINTER(vp)]),
+    "fdm_plan_reserve": (ci, [vp, ci, ci, ci]),
+    "fdm_plan_destroy": (ci, [vp]),
+    "fdm_plan_set_weights": (ci, [vp, C.c_char_p, vp, ll, vp]),
+    "fdm_plan_commit": (ci, [vp, vp]),
+    "fdm_audio_prepare": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp]),
+    "fdm_denoise_step": (ci, [vp, vp, ci, cf, vp, vp, vp]),
+    "fdm_sample_graph": (ci, [vp, C.POINTER(SampleArgs), vp]),
+    "fdm_plan_tune": (ci, [vp, vp]),
+    "fdm_plan_get": (ci, [vp, C.c_char_p, C.POINTER(ll)]),
+    "fdm_plan_set": (ci, [vp, C.c_char_p, ll]),
+    "fdm_schedule_host": (ci, [ci, vp]),
+    "fdm_ddim_schedule_host": (ci, [ci, ci, vp, vp, vp, vp]),
+    "fdm_alibi_slopes_host": (ci, [ci, vp]),
+    "fdm_pe_table_host": (ci, [ci, ci, ci, ci, vp]),
 }
 
 _lib = None

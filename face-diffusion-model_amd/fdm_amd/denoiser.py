@@ -1,130 +1,91 @@
-"""Denoiser + scheduler plan: the per-step FDM forward (models/fdm_vocaset.py:54-91,
-models/fdm_vqvae_mead.py:65-104) and the sampling loops (diffusion_BIWI_encoder_decoder.py:649-710,
-diffusion_mead_encoder_decoder.py:649-667) as one recorded HIP step program.
+"""Denoiser + scheduler plan: a thin binding of the library's plan layer (include/fdm_hip.h: fdm_plan_create,
+fdm_plan_set_weights, fdm_audio_prepare, fdm_denoise_step, fdm_sample_graph; implementation csrc/plan.hip).
 
-What runs where
-  * init (once per model): operand-dtype weight copies; tau table = Mish(W_t[:, t] + b_t) for all
-    1000 t (the one-hot GEMV of :71-72 is a column gather); per-layer time tables
-    TT_l[t] = Wo_l (Wv_l tau_t) of the cross-attention.
-  * prepare (once per batch of clips): AF = audio_extract(HuBERT features); per-layer tables
-    C1_l = Wo_l (Wv_l AF + bv_l) + bo_l; E0 = PE[l] + style[b] (+ emotion[b]).
-    The cross-attention's memory mask leaves exactly one key per query (models/fdm_vocaset.py:119-127), so
-    CA_l(h, AF + tau)[i] = C1_l[i] + TT_l[t] exactly (softmax over one key == 1).
-  * step program (captured into one hipGraph, replayed T times; t comes from a device counter):
-      latent_encoder GEMM(+bias+Mish+E0) -> 8 x { QKV GEMM (V scattered transposed) ->
-      fused causal-ALiBi attention -> out-proj GEMM(+bias+residual) -> fused LN1+LN2(+C1_l + TT_l[t]) ->
-      FFN1 GEMM(+bias+ReLU) -> FFN2 GEMM(+bias+residual) -> LN3 } -> latent_decoder GEMM ->
-      fused scheduler update (DDPM / DDIM, optional CFG mix, Philox or injected noise; also writes the
-      operand-dtype copy of x_{t-1} for the next step); the device-side step counter is advanced by one
-      thread of the step's first GEMM:
-      59 kernel launches per diffusion step (58 without CFG: the scheduler update then runs in the latent decoder
-      GEMM's epilogue); 51 / 50 in bf16 mode, where norm3 is folded into the QKV / out-proj /
-      latent-decoder GEMMs through per-row partial sums written by the FFN2 epilogue.
-torch only owns the device buffers and the stream."""
-import math
-import os
+The per-step FDM forward (models/fdm_vocaset.py:54-91, models/fdm_vqvae_mead.py:65-104) and the sampling loops
+(diffusion_BIWI_encoder_decoder.py:649-710, diffusion_mead_encoder_decoder.py:649-667) live in C++ / HIP:
+  * commit (once per model): operand-kind weight copies; tau table = Mish(W_t[:, t] + b_t) for all 1000 t (the one-hot
+    GEMV of :71-72 is a column gather); per-layer time tables TT_l[t] = Wo_l (Wv_l tau_t) of the folded cross-attention.
+  * prepare (once per batch of clips): AF = audio_extract(audio-encoder features); per-layer tables
+    C1_l = Wo_l (Wv_l AF + bv_l) + bo_l; E0 = PE[l] + style[b] (+ emotion[b]).  The cross-attention's memory mask leaves
+    exactly one key per query (models/fdm_vocaset.py:119-127), so CA_l(h, AF + tau)[i] = C1_l[i] + TT_l[t] exactly.
+  * step program (recorded once, captured into a hipGraph, `graph_steps` diffusion steps per graph launch; t comes from a
+    device counter): latent_encoder GEMM(+bias+Mish+E0) -> n_layers x { QKV GEMM (K / V written fragment-packed) -> fused
+    causal-ALiBi attention -> out-proj GEMM(+bias+residual) -> fused LN1+LN2(+C1_l + TT_l[t]) -> FFN1 GEMM(+bias+ReLU) ->
+    FFN2 GEMM(+bias+residual) -> LN3 } -> latent_decoder GEMM with the scheduler update (DDPM / DDIM, Philox or injected
+    noise) in its epilogue; CFG plans run cond + uncond rows through the same launches and mix in the scheduler kernel.
+This module only moves pointers: torch owns the caller-side tensors and the stream."""
+import ctypes as C
 
 import torch
 
-from . import ops, presets, schedule
-from ._lib import (ACT_MISH, ACT_NONE, ACT_RELU, BF16, F32, TILE_64x64, TILE_96x128, TILE_128x64, TILE_128x128,
-                   TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3,
-                   FdmError)
+from . import presets, schedule
+from ._lib import F32, FdmError, ModelDesc, SampleArgs, check, lib
+
+TILE_SITES = ("enc", "qkv", "qkv_ln", "out", "out_ln", "ffn1", "ffn2", "ffn2_stat", "dec", "dec_ln")
 
 
 def _dev(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def model_desc(p):
+    """fdm_model_desc of a presets.Preset (the reference constructors' numbers)."""
+    return ModelDesc(p.d, p.n_head, p.n_layers, p.ffn, p.G, p.c, p.n_style, p.n_emo, p.audio_in, p.pair,
+                     1 if p.pe == "periodic" else 0, p.period, int(p.latent_mish), int(p.style_mish), p.max_len)
+
+
 class DenoiserPlan:
-    # Persistent plan state (weights, tables, workspaces, counters) is created with inference mode OFF: callers may wrap
-    # sampling in torch.inference_mode() (the reference decorates its samplers with it) and later call again outside it;
-    # tensors born inside inference mode could not be refilled then.
-    @torch.inference_mode(False)
     def __init__(self, preset, weights, dtype=F32, device="cuda:0"):
         self.p = presets.get(preset)
         self.dtype = dtype
         self.device = torch.device(device)
-        self.td = ops.tdtype(dtype)
-        p, dv = self.p, self.device
-        if p.head_dim not in (64, 128, 256):
-            raise FdmError(f"denoiser head_dim {p.head_dim} unsupported (64, 128, 256)")
-        self.stream = torch.cuda.Stream(device=dv)
-        self.tiles, self._tune_rec, self._tile_cache, self._steps_seen = {}, None, {}, {}
-        w = {k: _dev(v, dv) for k, v in weights.items() if not k.startswith("audio_encoder.") and k != "PE.pe"}
-        self.w32 = w
-        need = ["audio_extract.0.weight", "audio_extract.2.weight", "time_embedd.0.weight", "style_embedd.weight",
-                "latent_encoder.0.weight", "latent_decoder.weight"]
-        for k in need:
-            if k not in w:
-                raise FdmError(f"missing weight {k}")
-        d = p.d
-        # operand-dtype copies of the per-step matrices
-        self.wt = {}
-        step_mats = ["latent_encoder.0.weight", "latent_decoder.weight"]
-        for l in range(p.n_layers):
-            pre = f"transformer_decoder.layers.{l}."
-            step_mats += [pre + "self_attn.in_proj_weight", pre + "self_attn.out_proj.weight",
-                          pre + "linear1.weight", pre + "linear2.weight"]
-        with torch.cuda.stream(self.stream):
-            for k in step_mats:
-                self.wt[k] = ops.to_operand(w[k], dtype)
-            # tau table [1000, d] = Mish(W_t^T + b_t)   (models/fdm_vocaset.py:71-72)
-            wtT = w["time_embedd.0.weight"].t().contiguous()
-            self.tau = torch.empty(1000, d, device=dv)
-            ops.bias_act(wtT, w["time_embedd.0.bias"], self.tau, 1000, d, ACT_MISH)
-            # per-layer time tables TT_l = (tau Wv^T) Wo^T   (fp32 MFMA, one-time)
-            self.TT, self.Wv, self.bv, self.Wo, self.bo = [], [], [], [], []
-            tmp = torch.empty(1000, d, device=dv)
-            for l in range(p.n_layers):
-                pre = f"transformer_decoder.layers.{l}.multihead_attn."
-                Wv = w[pre + "in_proj_weight"][2 * d:].contiguous()
-                bv = w[pre + "in_proj_bias"][2 * d:].contiguous()
-                Wo, bo = w[pre + "out_proj.weight"], w[pre + "out_proj.bias"]
-                tt = torch.empty(1000, d, device=dv)
-                ops.gemm(self.tau, Wv, 1000, d, d, out_f32=tmp)
-                ops.gemm(tmp, Wo, 1000, d, d, out_f32=tt)
-                self.TT.append(tt)
-                self.Wv.append(Wv); self.bv.append(bv); self.Wo.append(Wo); self.bo.append(bo)
-            # bf16 step program: norm3 of layer l-1 folded into the QKV / out-proj GEMMs of layer l and into the
-            # latent decoder (LN(x) W^T + b = rstd (x W'^T - mu colsum(W')) + (W beta + b), W' = W o gamma)
-            self.fuse_ln3 = dtype == BF16 and os.environ.get("FDM_FUSE_LN3", "1") == "1"
-            self.fold = {}
-            if self.fuse_ln3:
-                def fold(wname, bname, l_prev):
-                    pre = f"transformer_decoder.layers.{l_prev}.norm3."
-                    gam, bet = w[pre + "weight"], w[pre + "bias"]
-                    wp = ops.to_operand((w[wname] * gam.unsqueeze(0)).contiguous(), dtype)
-                    return dict(w=wp, colsum=wp.float().sum(1).contiguous(), bias=(w[wname] @ bet + w[bname]).contiguous(),
-                                gamma=gam, beta=bet)
-                for l in range(1, p.n_layers):
-                    pre = f"transformer_decoder.layers.{l}.self_attn."
-                    self.fold[l] = fold(pre + "in_proj_weight", pre + "in_proj_bias", l - 1)
-                self.fold["dec"] = fold("latent_decoder.weight", "latent_decoder.bias", p.n_layers - 1)
-            self.slopes = torch.tensor(schedule.alibi_slopes(p.n_head), dtype=torch.float32).to(dv)
-            self.pe = schedule.positional_table(d, p.pe, p.period, p.max_len + 30).to(dv)
-        self.stream.synchronize()
-        self.buf = {k: v.to(dv) for k, v in schedule.make_buffers(1000).items()}
-        c1, c2, sg = schedule.ddpm_tables(schedule.make_buffers(1000))
-        self.c1, self.c2, self.sigma = c1.to(dv), c2.to(dv), sg.to(dv)
+        if self.device.type != "cuda":
+            raise FdmError("DenoiserPlan runs on the HIP path only (no CPU fallback)")
+        self.h = None
         self.B = self.L = self.M = 0
-        self.default_chains = int(os.environ.get("FDM_CHAINS", "1"))
-        self._progs = {}
-        self._ddim = {}
+        self.cfg = False
+        self._keep, self._inputs = [], None
+        h = C.c_void_p()
+        desc = model_desc(self.p)
+        with torch.cuda.device(self.device):
+            check(lib().fdm_plan_create(C.byref(desc), 1, 1, 0, dtype, C.byref(h)))
+            self.h = h
+            # schedule tables and the positional table as the reference computes them (torch fp64 -> fp32, torch fp32
+            # sin / cos / exp), so that sampling is bit-identical to the reference's expressions; C-only callers get the
+            # library's own (fdm_schedule_host, fdm_pe_table_host: within 1 ulp of these)
+            buf = schedule.make_buffers(1000)
+            c1, c2, sg = schedule.ddpm_tables(buf)
+            tabs = {"sched.c1": c1, "sched.c2": c2, "sched.sigma": sg, "sched.sra": buf["sqrt_recip_alphas_cumprod"],
+                    "sched.srm1": buf["sqrt_recipm1_alphas_cumprod"],
+                    "PE.pe": schedule.positional_table(self.p.d, self.p.pe, self.p.period, self.p.max_len + 30)}
+            keep = []
+            for k, v in list(weights.items()) + list(tabs.items()):
+                if k.startswith("audio_encoder.") or (k == "PE.pe" and v is not tabs["PE.pe"]):
+                    continue        # (the PE buffer is rebuilt from the constructor's numbers, as the reference's __init__ does)
+                t = v.detach().to(torch.float32).contiguous()       # host or device memory: the plan copies it
+                keep.append(t)
+                check(lib().fdm_plan_set_weights(h, k.encode(), t.data_ptr(), t.numel(), _stream()))
+            torch.cuda.current_stream().synchronize()               # the copies read `keep`
+            check(lib().fdm_plan_commit(h, _stream()))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().fdm_plan_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------------------------------
-    @torch.inference_mode(False)
-    def prepare(self, hub, style, emo=None, L=None, cfg=False, chains=None):
-        """hub [B, N, 1024] HuBERT features; style [B, n_style]; emo [B, n_emo]; L latent frames.
-
-        chains: number of independent clip groups.  Clips never interact, so the step program is recorded
-        as `chains` dependency-free chains (one per clip group) that the captured hipGraph runs as
-        parallel branches: at M = B*L of a few hundred rows every kernel is latency-bound, and
-        overlapping the chains hides launch gaps and per-kernel fill/drain.  Results are independent
-        of the grouping (per-clip arithmetic never depends on the batch composition)."""
-        p, dv, d = self.p, self.device, self.p.d
+    def prepare(self, hub, style, emo=None, L=None, cfg=False):
+        """hub [B, N, fw] audio-encoder features; style [B, n_style]; emo [B, n_emo]; L latent frames."""
+        p, dv = self.p, self.device
         hub = _dev(hub, dv)
-        B, N = hub.shape[0], hub.shape[1]
+        B, N, fw = hub.shape
         nfa = N // p.pair
         L = nfa if L is None else min(L, nfa)
         if L < 1 or L > p.max_len:
@@ -138,400 +99,90 @@ class DenoiserPlan:
             if emo.dim() == 1:
                 emo = emo.unsqueeze(0).expand(B, -1)
             emo = _dev(emo, dv)
-        if chains is None:
-            chains = self.default_chains
-        chains = max(1, min(int(chains), B))
-        while B % chains:
-            chains -= 1
-        M = B * L
-        self.B, self.L, self.M, self.cfg = B, L, M, bool(cfg)
-        self.chains, self.Bc, self.Mc = chains, B // chains, (B // chains) * L
-        self.rep = 2 if cfg else 1                    # row replication: cond rows then uncond rows, per chain
-        self.Rc = self.Mc * self.rep
-        self.R = self.Rc * chains
-        self._progs = {}
-        w = self.w32
-        Mc, Rc, Bc = self.Mc, self.Rc, self.Bc
-        with torch.cuda.stream(self.stream):
-            # audio rows: pair HuBERT frames (models/fdm_vqvae_mead.py:73), crop to L (:64-66)
-            fw = hub.shape[2]                      # 1024 (HuBERT-large) or 768 (wav2vec2-base, BIWI)
-            if p.pair * fw != p.audio_in:
-                raise FdmError(f"audio feature width {fw} x pair {p.pair} != audio_extract input {p.audio_in}")
-            a = hub[:, : nfa * p.pair].reshape(B, nfa, p.pair * fw)[:, :L].reshape(M, p.pair * fw).contiguous()
-            t1 = torch.empty(M, d, device=dv)
-            AF = torch.empty(M, d, device=dv)
-            ops.gemm(a, w["audio_extract.0.weight"], M, d, p.audio_in, bias=w["audio_extract.0.bias"], act=ACT_MISH, out_f32=t1)
-            ops.gemm(t1, w["audio_extract.2.weight"], M, d, d, bias=w["audio_extract.2.bias"], out_f32=AF)
-            self.AF = AF
-            # folded cross-attention tables C1_l, chain layout [chains][rep][Mc, d]
-            self.C1 = []
-            c1 = torch.empty(M, d, device=dv)
-            for l in range(p.n_layers):
-                ops.gemm(AF, self.Wv[l], M, d, d, bias=self.bv[l], out_f32=t1)
-                ops.gemm(t1, self.Wo[l], M, d, d, bias=self.bo[l], out_f32=c1)
-                self.C1.append(c1.view(chains, 1, Mc, d).expand(chains, self.rep, Mc, d).reshape(self.R, d).clone())
-            # conditioning addend E0 = PE[l] + style[b] (+ emotion[b])  (:75-84), same chain layout
-            sty = torch.empty(B, d, device=dv)
-            ops.small_linear(style, w["style_embedd.weight"], w["style_embedd.bias"], sty, B, p.n_style, d,
-                             ACT_MISH if p.style_mish else ACT_NONE)
-            self.E0 = torch.empty(self.R, d, device=dv)
-            em = emu = None
-            if p.n_emo:
-                em = torch.empty(B, d, device=dv)
-                ops.small_linear(emo, w["emotion_embedd.weight"], w["emotion_embedd.bias"], em, B, p.n_emo, d)
-                if cfg:   # null condition = zeros_like(emotion one-hot) (models/fdm_vqvae_mead.py:56-57) -> bias only
-                    emu = torch.empty(B, d, device=dv)
-                    ops.small_linear(torch.zeros_like(emo), w["emotion_embedd.weight"], w["emotion_embedd.bias"], emu, B, p.n_emo, d)
-            for c in range(chains):
-                for r in range(self.rep):
-                    e = None if em is None else (emu if r == 1 else em)
-                    dst = self.E0[c * Rc + r * Mc:]
-                    if e is None:
-                        ops.add_rows(dst, Mc, d, self.pe, 1, L, sty[c * Bc:], L, Bc)
-                    else:
-                        ops.add_rows(dst, Mc, d, self.pe, 1, L, sty[c * Bc:], L, Bc, e[c * Bc:], L, Bc)
-            self._alloc_workspace()
-        self.tiles = dict(self._tile_cache.get((self.Rc, self.Mc, self.L, self.rep), {}))
-        self.stream.synchronize()
+        with torch.cuda.device(dv):
+            check(lib().fdm_audio_prepare(self.h, hub.data_ptr(), B, N, fw, style.data_ptr(),
+                                          emo.data_ptr() if p.n_emo else None, L, int(bool(cfg)), _stream()))
+        # the library reads hub / style / emo asynchronously on this stream: keep them alive until the next prepare
+        self._inputs = (hub, style, emo)
+        self.B, self.L, self.M, self.cfg = B, L, B * L, bool(cfg)
         return L
-
-    def _alloc_workspace(self):
-        p, dv, d = self.p, self.device, self.p.d
-        R, td = self.R, self.td
-        z = lambda *s, dt=torch.float32: torch.zeros(*s, device=dv, dtype=dt)
-        self.Lpad = ops.kv_pad(self.L)
-        ws = dict(h=z(R, d), h2=z(R, d), x1=z(R, d), x0=z(R, d), x=z(self.M, d))
-        split = ops.is_split(self.dtype)
-        # operand-kind matrices (GEMM inputs): plain tensors, or hi/lo plane pairs in the split modes
-        zt = (lambda r, c: ops.Split.empty(r, c, self.dtype, dv)) if split else (lambda r, c: z(r, c, dt=td))
-        if self.dtype != F32:
-            ws.update(xt=zt(self.M, d), ht=zt(R, d), h2t=zt(R, d))
-        else:   # fp32 operands alias the fp32 residual-stream buffers
-            ws.update(xt=ws["x"], ht=ws["h"], h2t=ws["h2"])
-        if self.fuse_ln3:
-            ws.update(x2=z(R, d), x2t=z(R, d, dt=td), stats=z(self.chains, d // 64, self.Rc, 2))
-        # q: row-major queries; kp / vp: fragment-packed keys / values written by the QKV GEMM's epilogue (zeroed: pad keys)
-        # (split modes: attention runs in fp32 -- Q / K / V leave the QKV GEMM as fp32, ctx returns as a plane pair)
-        ta = torch.float32 if split else td
-        ws.update(q=z(R, d, dt=ta), ctx=zt(R, d), u=zt(R, p.ffn),
-                  kp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=ta),
-                  vp=z(self.B * self.rep * p.n_head, self.Lpad * p.head_dim, dt=ta))
-        self.ws = ws
-        # per chain: [device-side step counter, t of the current step]; both written by one thread of the step's first GEMM
-        self.step = torch.zeros(2 * self.chains, dtype=torch.int32, device=dv)
-        self.tseq = torch.zeros(1024, dtype=torch.int32, device=dv)
-
-    # ------------------------------------------------------------------------------------------
-    # ------------------------------------------------------------------------------------------
-    def _gemm(self, label, *a, **kw):
-        """One of the step's GEMM call sites; `label` keys the plan-time tile choice."""
-        if self._tune_rec is not None:
-            self._tune_rec.setdefault(label, []).append((a, dict(kw)))
-        ops.gemm(*a, tile=self.tiles.get(label, 0), **kw)
-
-    def tune(self):
-        """Tune the GEMM tiles for the prepared shape now (plan-time work; sampling calls otherwise do it lazily)."""
-        self._tune_tiles()
-
-    def _tune_tiles(self, n_steps=None):
-        """Time the candidate output tiles of every GEMM call site of the step at this plan's shapes and keep the
-        fastest.  Each candidate runs the call site's 8 per-layer instances (distinct weights, so they come from
-        beyond L2 as they do inside the step) as a replayed graph; ~50 ms in all, cached per shape, and only done for
-        shapes the plan keeps being used at (after 2000 steps at the shape; n_steps=None forces, as bench.py does).  Every tile accumulates k in the
-        same order, so the choice changes speed only, never results.  FDM_TUNE=0 keeps the library heuristic."""
-        key = (self.Rc, self.Mc, self.L, self.rep)
-        if os.environ.get("FDM_TUNE", "1") == "0" or key in self._tile_cache:
-            return
-        if n_steps is not None:
-            # lazy: the ~0.2 s of tuning repays itself after a few thousand diffusion steps, so a plan tunes a shape only
-            # once it has already run 2000 steps at it (repeated / served use); one-shot calls never pay.  n_steps=None forces.
-            seen = self._steps_seen.get(key, 0)
-            self._steps_seen[key] = seen + n_steps
-            if seen < 2000:
-                return
-        self.tiles, self._tune_rec = {}, {}
-        import time as _time
-        _t0 = _time.perf_counter()
-        with torch.cuda.stream(self.stream):
-            with ops.Program():            # dry recording of one chain: captures each call site's arguments, runs nothing
-                self._record_chain(0)
-            calls, self._tune_rec = self._tune_rec, None
-
-            def timed(inst, tile):
-                prog = ops.Program()
-                with prog:
-                    for a, kw in inst:
-                        ops.gemm(*a, tile=tile, **kw)
-                prog.instantiate()
-                prog.replay(2)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                prog.replay(5)
-                e1.record()
-                e1.synchronize()
-                return e0.elapsed_time(e1)
-
-            runner_up = {}
-            for label, inst in calls.items():
-                inst = [(a, {k: v for k, v in kw.items() if k != "incr_counter"}) for a, kw in inst]
-                while len(inst) < 4:
-                    inst = inst + inst
-                base = min(timed(inst, 0), timed(inst, 0), timed(inst, 0))
-                cand = [(base * 0.97, 0)]               # switch only for a > 3 % gain over the heuristic
-                for tile in (TILE_64x64, TILE_64x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_128x64, TILE_128x64_S3, TILE_128x128, TILE_96x128) + ((TILE_256x128,) if self.Rc >= 1024 else ()):
-                    cand.append((min(timed(inst, tile), timed(inst, tile), timed(inst, tile)), tile))
-                cand.sort()
-                self.tiles[label] = cand[0][1]
-                if len(cand) > 1 and cand[1][0] < cand[0][0] * 1.05:
-                    runner_up[label] = cand[1][1]       # too close to call in isolation: settled inside the chain below
-            # the isolated timings can mislead (cache state inside the step differs): keep the tuned set only if one
-            # whole denoiser pass of a clip group is faster with it than with the heuristic
-            tuned = dict(self.tiles)
-
-            def chain_time(tiles):
-                self.tiles = tiles
-                self.step.zero_()
-                prog = ops.Program()
-                with prog:
-                    self._record_chain(0)
-                prog.instantiate()
-                prog.replay(2)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                prog.replay(4)
-                e1.record()
-                e1.synchronize()
-                return e0.elapsed_time(e1)
-
-            if any(tuned.values()) or runner_up:
-                t_h = min(chain_time({}), chain_time({}))
-                t_t = min(chain_time(tuned), chain_time(tuned))
-                for label, alt in runner_up.items():      # close calls: try the runner-up in place, keep what the chain prefers
-                    trial = dict(tuned, **{label: alt})
-                    t_a = min(chain_time(trial), chain_time(trial))
-                    if t_a < 0.997 * t_t:
-                        tuned, t_t = trial, t_a
-                self.tiles = tuned if t_t < 0.995 * t_h else {}
-                if os.environ.get("FDM_TUNE_VERBOSE"):
-                    print(f"[fdm tune] rows={self.Rc} candidates={tuned} chain {t_h / 4:.3f} -> {t_t / 4:.3f} ms: "
-                          f"{'kept' if self.tiles else 'rejected'} ({_time.perf_counter() - _t0:.2f} s)", flush=True)
-        ov = os.environ.get("FDM_TILE_OVERRIDE")      # experiments: "qkv_ln=5,ffn1=3" forces call sites after the tuning
-        if ov:
-            self.tiles = dict(self.tiles, **{k: int(v) for k, v in (kv.split("=") for kv in ov.split(","))})
-        self._tile_cache[key] = dict(self.tiles)
-        self._progs = {}                   # programs recorded with the old tiles are rebuilt
-
-    def _record_chain(self, c, sched=None):
-        """Record the denoiser pass of clip group c: ws['x'] rows of the group -> ws['x0'] rows of the group.
-        sched (fdm_sched_args, non-CFG samplers): the latent-decoder GEMM applies the scheduler update in its epilogue
-        and writes x_{t-1} straight into ws['x'] (+ its operand copy): x0 is not materialised, one launch less."""
-        p, d, ws, w, wt = self.p, self.p.d, self.ws, self.w32, self.wt
-        Mc, Rc, Bc, L = self.Mc, self.Rc, self.Bc, self.L
-        xr, rb = c * Mc, c * Rc                         # first row of the group in x / in the decoder-stack buffers
-        both = self.dtype != F32
-        step, tcur = self.step[2 * c:], self.step[2 * c + 1:]
-        # (the operand-dtype copy ws['xt'] of x is written by the scheduler kernel of the previous step and by
-        #  _load_x() before the first one)
-        for r in range(self.rep):
-            o = rb + r * Mc
-            self._gemm("enc", ws["xt"][xr:], wt["latent_encoder.0.weight"], Mc, d, d, bias=w["latent_encoder.0.bias"],
-                     act=ACT_MISH if p.latent_mish else ACT_NONE, resid=self.E0[o:], out_f32=ws["h"][o:],
-                     out_t=ws["ht"][o:] if both else None,
-                     incr_counter=step if r == 0 else None, incr_table=self.tseq if r == 0 else None)
-            # (first kernel of the step: step counter += 1, tcur = tseq[step])
-        BBc = Bc * self.rep
-        kp, vp = ws["kp"][c * BBc * p.n_head:], ws["vp"][c * BBc * p.n_head:]
-        kv = dict(out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=self.Lpad, kv_hd=p.head_dim)
-        if ops.is_split(self.dtype):
-            kv.update(out_f32=ws["q"][rb:], ldo_f32=d)
-        else:
-            kv.update(out_t=ws["q"][rb:], ldo_t=d)
-        fuse = self.fuse_ln3
-        st = ws["stats"][c] if fuse else None
-        np_, eps = d // 64, 1e-5
-        for l in range(p.n_layers):
-            pre = f"transformer_decoder.layers.{l}."
-            f = self.fold.get(l) if fuse else None
-            if f is None:      # layer input h (fp32) / ht (operand copy) are materialised
-                self._gemm("qkv", ws["ht"][rb:], wt[pre + "self_attn.in_proj_weight"], Rc, 3 * d, d, bias=w[pre + "self_attn.in_proj_bias"], **kv)
-            else:              # layer input = LN3(x2) of the previous layer, never materialised
-                self._gemm("qkv_ln", ws["x2t"][rb:], f["w"], Rc, 3 * d, d, bias=f["bias"], **kv,
-                         ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
-            ops.attention(ws["q"][rb:], kp, vp, ws["ctx"][rb:], B=BBc, H=p.n_head, L=L, hd=p.head_dim,
-                          ldq=d, ldo=d, Lpad=self.Lpad, scale=1.0 / math.sqrt(p.head_dim), causal=True,
-                          slopes=self.slopes, period=p.period)
-            if f is None:
-                self._gemm("out", ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
-                           resid=ws["h"][rb:], out_f32=ws["x1"][rb:])
-            else:
-                self._gemm("out_ln", ws["ctx"][rb:], wt[pre + "self_attn.out_proj.weight"], Rc, d, d, bias=w[pre + "self_attn.out_proj.bias"],
-                           resid=ws["x2"][rb:], out_f32=ws["x1"][rb:], ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps,
-                         rln_gamma=f["gamma"], rln_beta=f["beta"])
-            # norm1 and norm2 back to back in one kernel: h2 = LN2(LN1(x1) + C1_l + TT_l[t])
-            ops.layernorm(ws["x1"][rb:], w[pre + "norm1.weight"], w[pre + "norm1.bias"], Rc, d, add_mat=self.C1[l][rb:],
-                          add_tab=self.TT[l], tab_index=None, tab_step=tcur, y_f32=ws["h2"][rb:],
-                          y_t=ws["h2t"][rb:] if both else None, dtype=self.dtype,
-                          gamma2=w[pre + "norm2.weight"], beta2=w[pre + "norm2.bias"])
-            self._gemm("ffn1", ws["h2t"][rb:], wt[pre + "linear1.weight"], Rc, p.ffn, d, bias=w[pre + "linear1.bias"], act=ACT_RELU,
-                     out_t=ws["u"][rb:])
-            if fuse:           # x2 = h2 + FFN(h2): fp32 + operand copy + per-row partial sums for the folded norm3
-                # (producer of the folded-norm3 partial sums: written per 64-column group in a tile-independent order)
-                self._gemm("ffn2_stat", ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"],
-                           resid=ws["h2"][rb:], out_f32=ws["x2"][rb:], out_t=ws["x2t"][rb:], stat_out=st)
-            else:
-                self._gemm("ffn2", ws["u"][rb:], wt[pre + "linear2.weight"], Rc, d, p.ffn, bias=w[pre + "linear2.bias"], resid=ws["h2"][rb:],
-                           out_f32=ws["x1"][rb:])
-                ops.layernorm(ws["x1"][rb:], w[pre + "norm3.weight"], w[pre + "norm3.bias"], Rc, d, y_f32=ws["h"][rb:],
-                              y_t=ws["ht"][rb:] if both else None, dtype=self.dtype)
-        if sched is not None:      # x_{t-1} = update(x0_hat = this GEMM, x_t = ws['x']) in the epilogue
-            out = dict(resid=ws["x"][xr:], out_f32=ws["x"][xr:], out_t=ws["xt"][xr:] if both else None, sched=sched)
-        else:
-            out = dict(out_f32=ws["x0"][rb:])
-        if fuse:
-            f = self.fold["dec"]
-            self._gemm("dec_ln", ws["x2t"][rb:], f["w"], Rc, d, d, bias=f["bias"], **out,
-                       ln_stat_in=st, ln_nparts=np_, ln_dim=d, ln_eps=eps, ln_colsum=f["colsum"])
-        else:
-            self._gemm("dec", ws["ht"][rb:], wt["latent_decoder.weight"], Rc, d, d, bias=w["latent_decoder.bias"], **out)
-
-    def _program(self, kind, **kw):
-        """Build (once) the step program `kind` in {'pass', 'ddpm', 'ddim'}: one lane per clip group."""
-        key = (kind,) + tuple(sorted((k, (v.data_ptr() if torch.is_tensor(v) else v)) for k, v in kw.items()))
-        if key in self._progs:
-            return self._progs[key]
-        d, ws, Mc, Rc = self.p.d, self.ws, self.Mc, self.Rc
-        n = Mc * d
-        prog = ops.Program()
-        with prog:
-            fuse_sched = (not self.cfg) and kind in ("ddpm", "ddim") and os.environ.get("FDM_FUSE_SCHED", "1") != "0"
-            for c in range(self.chains):
-                prog.lane(c)
-                x0 = ws["x0"][c * Rc:]
-                x0u = ws["x0"][c * Rc + Mc:] if self.cfg else None
-                x = ws["x"][c * Mc:]
-                xt = ws["xt"][c * Mc:] if self.dtype != F32 else None
-                step = self.step[2 * c:]
-                skw = None
-                if kind == "ddpm":
-                    nz = kw.get("noise")
-                    skw = dict(mode=0, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
-                               n_per_clip=self.L * d, tseq=self.tseq, step=step, advance=0,
-                               c1=self.c1, c2=self.c2, sigma=self.sigma,
-                               noise=None if nz is None else nz.view(-1)[c * n:], noise_stride=self.M * d,
-                               seed=kw.get("seed", 0), clip0=kw.get("clip0", 0) + c * self.Bc)
-                elif kind == "ddim":
-                    skw = dict(mode=1, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0),
-                               tseq=self.tseq, step=step, advance=0, sra=self.buf["sqrt_recip_alphas_cumprod"],
-                               srm1=self.buf["sqrt_recipm1_alphas_cumprod"], sqrt_an=kw["sqrt_an"], c_n=kw["c_n"])
-                if skw is not None and fuse_sched:
-                    # non-CFG samplers: the update runs in the latent decoder GEMM's epilogue (bit-identical, one launch less)
-                    mode = skw.pop("mode")
-                    self._record_chain(c, sched=ops.sched_args(mode, None, None, None, n, **skw))
-                    continue
-                self._record_chain(c)
-                if skw is not None:
-                    mode = skw.pop("mode")
-                    ops.sched_step(mode, x0, x, x, n, x_out_t=xt, **skw)
-                elif kind == "pass" and self.cfg:
-                    ops.sched_step(2, x0, None, x0, n, x0u=x0u, cfg_scale=kw.get("cfg_scale", 0.0))
-        prog.hold(*[v for v in kw.values() if torch.is_tensor(v)])
-        if len(self._progs) >= 8:          # programs are keyed by the pointers they captured (e.g. injected noise): cap the cache
-            self._progs.pop(next(iter(self._progs)))
-        self._progs[key] = prog
-        return prog
-
-    def _x0_rows(self):
-        """The (cond / CFG-mixed) x0 rows in clip order [M, d]."""
-        if self.rep == 1:
-            return self.ws["x0"]
-        return self.ws["x0"].view(self.chains, self.rep, self.Mc, self.p.d)[:, 0].reshape(self.M, self.p.d)
-
-    @torch.inference_mode(False)
-    def _set_steps(self, ts):
-        if len(ts) > self.tseq.numel():
-            self.tseq = torch.zeros(len(ts), dtype=torch.int32, device=self.device)
-            self._progs = {}
-        self.tseq[: len(ts)].copy_(torch.tensor(ts, dtype=torch.int32))
-        self.step.fill_(-1)          # the first GEMM of every step increments it before anything reads it
-
-    def _load_x(self, x):
-        self.ws["x"].copy_(x.reshape(self.M, self.p.d))
-        if self.dtype != F32:
-            ops.cast(self.ws["x"], self.ws["xt"])
-
-    def _run(self, prog, n_steps, use_graph):
-        if use_graph and os.environ.get("FDM_EAGER_LANES") == "1":
-            prog.run_lanes(n_steps)
-        elif use_graph:
-            prog.instantiate()
-            prog.replay(n_steps)
-        else:
-            for _ in range(n_steps):
-                prog.run()
-
-    # ------------------------------------------------------------------------------------------
-    def denoise(self, x, t, cfg_scale=2.5):
-        """One FDM.forward: x [B, L*G, c] -> x0_hat [B, L*G, c] (CFG-mixed when prepared with cfg=True)."""
-        self._check_x(x)
-        cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            self._load_x(x)
-            self._set_steps([int(t)])
-            self._program("pass", cfg_scale=float(cfg_scale)).run()
-            out = self._x0_rows().clone().reshape(x.shape)
-        cur.wait_stream(self.stream)
-        return out
 
     def _check_x(self, x):
         if self.M == 0:
             raise FdmError("call prepare() first")
         if tuple(x.shape) != (self.B, self.L * self.p.G, self.p.c):
             raise FdmError(f"latent shape {tuple(x.shape)} != {(self.B, self.L * self.p.G, self.p.c)}")
+        return _dev(x, self.device)
 
-    def sample_ddpm(self, x_T, t_list, noise=None, seed=0, clip0=0, cfg_scale=2.5, use_graph=True, record=None):
-        """p_sample_loop over t_list (descending).  noise [len(t_list), B, L*G, c] injects z per step;
-        otherwise z is drawn in-kernel (Philox keyed by seed, global clip index clip0 + b, step)."""
-        self._check_x(x_T)
-        cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(cur)
-        self._tune_tiles(len(t_list))
-        with torch.cuda.stream(self.stream):
-            self._load_x(x_T)
-            self._set_steps(list(t_list))
-            kw = dict(cfg_scale=float(cfg_scale), clip0=int(clip0))
-            if noise is not None:
-                kw["noise"] = _dev(noise, self.device)
-            else:
-                kw["seed"] = int(seed)
-            prog = self._program("ddpm", **kw)
-            if record is None:
-                self._run(prog, len(t_list), use_graph)
-            else:
-                for _ in t_list:
-                    self._run(prog, 1, use_graph)
-                    record.append(self.ws["x"].clone().reshape(x_T.shape))
-            out = self.ws["x"].clone().reshape(x_T.shape)
-        cur.wait_stream(self.stream)
+    # ------------------------------------------------------------------------------------------
+    def denoise(self, x, t, cfg_scale=2.5, return_uncond=False):
+        """One FDM.forward: x [B, L*G, c] -> x0_hat [B, L*G, c] (CFG-mixed when prepared with cfg=True)."""
+        x = self._check_x(x)
+        out = torch.empty_like(x)
+        unc = torch.empty_like(x) if (return_uncond and self.cfg) else None
+        with torch.cuda.device(self.device):
+            check(lib().fdm_denoise_step(self.h, x.data_ptr(), int(t), float(cfg_scale), out.data_ptr(),
+                                         unc.data_ptr() if unc is not None else None, _stream()))
+        return (out, unc) if return_uncond else out
+
+    def _sample(self, a, x_T):
+        x = self._check_x(x_T)
+        out = torch.empty_like(x)
+        a.x_T, a.out = x.data_ptr(), out.data_ptr()
+        with torch.cuda.device(self.device):
+            check(lib().fdm_sample_graph(self.h, C.byref(a), _stream()))
         return out
 
-    def sample_ddim(self, x_T, steps, cfg_scale=2.5, use_graph=True):
-        """ddim_sample (eta = 0).  The last pair (t, -1) never updates the latent in the reference
-        (:695-696), so its denoiser call is skipped: exact."""
-        self._check_x(x_T)
-        if steps not in self._ddim:
-            pairs = [pr for pr in schedule.ddim_time_pairs(steps) if pr[1] >= 0]
-            san, cn = schedule.ddim_tables(schedule.make_buffers(1000), pairs)
-            self._ddim[steps] = (pairs, san.to(self.device), cn.to(self.device))
-        pairs, san, cn = self._ddim[steps]
-        cur = torch.cuda.current_stream(self.device)
-        self.stream.wait_stream(cur)
-        self._tune_tiles(len(pairs))
-        with torch.cuda.stream(self.stream):
-            self._load_x(x_T)
-            self._set_steps([pr[0] for pr in pairs])
-            prog = self._program("ddim", cfg_scale=float(cfg_scale), sqrt_an=san, c_n=cn)
-            self._run(prog, len(pairs), use_graph)
-            out = self.ws["x"].clone().reshape(x_T.shape)
-        cur.wait_stream(self.stream)
+    def sample_ddpm(self, x_T, t_list, noise=None, seed=0, clip0=0, cfg_scale=2.5, use_graph=True, record=None, graph_steps=0):
+        """p_sample_loop over t_list (descending).  noise [len(t_list), B, L*G, c] injects z per step; otherwise z is
+        drawn in-kernel (Philox keyed by seed, global clip index clip0 + b, step).  record (a list) receives the latent
+        after every step."""
+        a = SampleArgs()
+        ts = (C.c_int * len(t_list))(*[int(t) for t in t_list])
+        a.kind, a.t_list, a.n_steps = 0, C.cast(ts, C.c_void_p), len(t_list)
+        a.seed, a.clip0, a.cfg_scale, a.eager, a.graph_steps = int(seed), int(clip0), float(cfg_scale), int(not use_graph), int(graph_steps)
+        if noise is not None:
+            nz = _dev(noise, self.device)
+            if nz.numel() != len(t_list) * self.M * self.p.d:
+                raise FdmError("noise must be [len(t_list), B, L*G, c]")
+            self._keep = (self._keep + [nz])[-8:]          # recorded programs (at most 8) point at it
+            a.noise = nz.data_ptr()
+        rec = None
+        if record is not None:
+            rec = torch.empty(len(t_list), *x_T.shape, device=self.device)
+            a.record = rec.data_ptr()
+        out = self._sample(a, x_T)
+        if rec is not None:
+            record.extend(rec[i] for i in range(len(t_list)))
         return out
+
+    def sample_ddim(self, x_T, steps, cfg_scale=2.5, use_graph=True, graph_steps=0):
+        """ddim_sample (eta = 0).  The last pair (t, -1) never updates the latent in the reference (:695-696), so its
+        denoiser call is skipped: exact."""
+        a = SampleArgs()
+        a.kind, a.ddim_steps, a.cfg_scale, a.eager, a.graph_steps = 1, int(steps), float(cfg_scale), int(not use_graph), int(graph_steps)
+        return self._sample(a, x_T)
+
+    # ------------------------------------------------------------------------------------------
+    def tune(self):
+        """Tune the GEMM tiles for the prepared shape now (plan-time work; sampling calls otherwise do it lazily, once a
+        shape has run 2000 steps)."""
+        with torch.cuda.device(self.device):
+            check(lib().fdm_plan_tune(self.h, _stream()))
+
+    def get(self, key):
+        v = C.c_longlong()
+        check(lib().fdm_plan_get(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    def set(self, key, value):
+        check(lib().fdm_plan_set(self.h, key.encode(), int(value)))
+
+    @property
+    def tiles(self):
+        """Tile chosen per GEMM call site of the step (0 = library heuristic)."""
+        return {k: self.get("tile." + k) for k in TILE_SITES}
+
+    @property
+    def fuse_ln3(self):
+        return bool(self.get("fuse_ln3"))

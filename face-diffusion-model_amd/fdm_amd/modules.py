@@ -24,15 +24,25 @@ import torch
 import torch.nn as nn
 
 from . import ops, presets, schedule, synth
-from ._lib import BF16, F32, FdmError
+from ._lib import BF16, DTYPE_NAMES, F32, FdmError
 from .denoiser import DenoiserPlan
 from .hubert import HUBERT_LARGE, WAV2VEC2_BASE, HubertPlan, num_frames
 from .vq import VQPlan
 
 
 def compute_dtype(name=None):
-    name = name or os.environ.get("FDM_AMD_DTYPE", "fp32")
-    return BF16 if name.lower() in ("bf16", "bfloat16") else F32
+    """Arithmetic mode of the HIP path: "fp32" (default; exact fp32 MFMA), "f16x3" (split-fp16 operands on the 16-bit matrix
+    cores: same 1e-4 contract, ~1.6x the frames/s), "bf16" (throughput mode, BASELINE.json configs[1]), "bf16x3" (comparison)."""
+    name = (name or os.environ.get("FDM_AMD_DTYPE", "fp32")).lower()
+    name = {"fp32": "f32", "float32": "f32", "bfloat16": "bf16"}.get(name, name)
+    if name not in DTYPE_NAMES:
+        raise FdmError(f"unknown compute dtype {name!r} (one of {sorted(DTYPE_NAMES)})")
+    return DTYPE_NAMES[name]
+
+
+def _side_dtype(dt):
+    """The once-per-clip stages (audio encoder, VQ quant / decode) run in fp32 when the step program uses split operands."""
+    return dt if dt in (F32, BF16) else F32
 
 
 class ParamTree(nn.Module):
@@ -55,8 +65,26 @@ class ParamTree(nn.Module):
         return super()._load_from_state_dict(*a, **k)
 
 
-def _tensor_key(t):
-    return None if t is None else (t.data_ptr(), tuple(t.shape), t._version, str(t.device))
+class _TensorKey:
+    """Identity of a cached input: the tensor OBJECT (kept alive here, so the caching allocator cannot hand its address to
+    another clip) plus its version counter (in-place writes invalidate the cache)."""
+
+    def __init__(self, t):
+        self.t, self.version = t, (None if t is None else t._version)
+
+    def matches(self, t):
+        return t is self.t and (t is None or t._version == self.version)
+
+
+def _scalar_t(t):
+    """All clips of a call share the diffusion timestep (the reference runs B = 1); mixed timesteps would silently take
+    clip 0's, so they are rejected."""
+    if not torch.is_tensor(t):
+        return int(t)
+    f = t.flatten()
+    if f.numel() > 1 and bool((f != f[0]).any()):
+        raise FdmError("per-clip timesteps are not supported on this path: all clips of a call share t")
+    return int(f[0])
 
 
 # --------------------------------------------------------------------------------------------------
@@ -91,7 +119,12 @@ class HubertModel(ParamTree):
 
     @classmethod
     def from_pretrained(cls, path=None, *a, **k):
+        """Loads a local HF checkpoint directory (no network here); a missing directory keeps the seeded random init and
+        says so.  Accepts the `hubert.` / `wav2vec2.` key prefixes of the *ForCTC checkpoints and the torch-2.0
+        weight-norm names (weight_g / weight_v) of the positional conv."""
+        import warnings
         m = cls()
+        loaded = 0
         if path and os.path.isdir(str(path)):
             for fn in ("model.safetensors", "pytorch_model.bin"):
                 fp = os.path.join(str(path), fn)
@@ -101,16 +134,33 @@ class HubertModel(ParamTree):
                         sd = load_file(fp)
                     else:
                         sd = torch.load(fp, map_location="cpu")
-                    sd = {kk[len("hubert."):] if kk.startswith("hubert.") else kk: vv for kk, vv in sd.items()}
-                    sd = {kk.replace("conv.weight_g", "conv.parametrizations.weight.original0")
-                            .replace("conv.weight_v", "conv.parametrizations.weight.original1"): vv for kk, vv in sd.items()}
-                    m.load_state_dict(sd, strict=False)
+                    loaded = m.load_hf_state_dict(sd)
                     break
+        if not loaded:
+            warnings.warn(f"{cls.__name__}.from_pretrained({path!r}): no checkpoint found, keeping the seeded random init")
         return m
+
+    def load_hf_state_dict(self, sd):
+        """Key-normalise and load; returns the number of tensors taken.  A shape mismatch raises (strict=False does not
+        cover shapes), so a HuBERT checkpoint cannot be loaded into the wav2vec2-base encoder by accident."""
+        out = {}
+        for kk, vv in sd.items():
+            for pre in ("hubert.", "wav2vec2."):
+                if kk.startswith(pre):
+                    kk = kk[len(pre):]
+            kk = kk.replace("conv.weight_g", "conv.parametrizations.weight.original0").replace("conv.weight_v", "conv.parametrizations.weight.original1")
+            out[kk] = vv
+        own = self.state_dict()
+        take = {kk: vv for kk, vv in out.items() if kk in own}
+        for kk, vv in take.items():
+            if tuple(vv.shape) != tuple(own[kk].shape):
+                raise FdmError(f"checkpoint tensor {kk} has shape {tuple(vv.shape)}, this encoder expects {tuple(own[kk].shape)}")
+        self.load_state_dict(take, strict=False)
+        return len(take)
 
     def _get_plan(self, device):
         if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
-            self._plan = HubertPlan(self.state_dict(), self.n_layers, self._dtype, device)
+            self._plan = HubertPlan(self.state_dict(), self.n_layers, _side_dtype(self._dtype), device)
             self._plan_stale = False
         return self._plan
 
@@ -144,7 +194,7 @@ class Wav2Vec2Model(HubertModel):
 
     def _get_plan(self, device):
         if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
-            self._plan = HubertPlan(self.state_dict(), self.n_layers, self._dtype, device, cfg=WAV2VEC2_BASE)
+            self._plan = HubertPlan(self.state_dict(), self.n_layers, _side_dtype(self._dtype), device, cfg=WAV2VEC2_BASE)
             self._plan_stale = False
         return self._plan
 
@@ -168,14 +218,21 @@ class _FDMBase(ParamTree):
         self.latent_decoder.bias.data.zero_()
         n_pe = 630 if self.preset.pe == "periodic" else 5000
         self._register("PE.pe", schedule.positional_table(feature_dim, self.preset.pe, self.preset.period, n_pe).unsqueeze(0), buffer=True)
-        enc_cls = Wav2Vec2Model if self.preset_name == "biwi" else HubertModel     # models/fdm.py:19 vs models/fdm_vocaset.py:17
-        self.audio_encoder = enc_cls.from_pretrained("/data/WX/hubert-large-ls960-ft") if audio_encoder else None
+        # models/fdm.py:18-19 (wav2vec2-base-960h) vs models/fdm_vocaset.py:17 (hubert-large-ls960-ft)
+        enc_cls, enc_path = (Wav2Vec2Model, "/data/WX/wav2vec2-base-960h") if self.preset_name == "biwi" else (HubertModel, "/data/WX/hubert-large-ls960-ft")
+        if audio_encoder:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")       # the constructor's default path is the reference author's machine
+                self.audio_encoder = enc_cls.from_pretrained(enc_path)
+        else:
+            self.audio_encoder = None
         self.one_hot_timesteps = None
         self._dtype = compute_dtype(dtype)
         self._plan = None
         self._plan_stale = True
         self._prep_key = None
-        self._hub_key, self._hub = None, None
+        self._hub_key, self._hub = None, None          # _TensorKey of the encoded audio / "injected"
 
     # -- plan management --------------------------------------------------------------------
     def plan(self, device):
@@ -193,23 +250,24 @@ class _FDMBase(ParamTree):
     def audio_features(self, audio):
         if self._hub_key == "injected":
             return self._hub
-        key = _tensor_key(audio)
-        if key != self._hub_key:      # step-invariant: computed once per audio tensor (hoisted, exact)
+        if not (isinstance(self._hub_key, _TensorKey) and self._hub_key.matches(audio)):
+            # step-invariant: computed once per audio tensor OBJECT (hoisted, exact); a new tensor -- even one the
+            # allocator placed at the same address -- is encoded again
             self._hub = self.audio_encoder(audio).last_hidden_state
-            self._hub_key = key
+            self._hub_key = _TensorKey(audio)
         return self._hub
 
     def prepare(self, audio, L, style, emo=None, cfg=False):
         hub = self.audio_features(audio)
         plan = self.plan(hub.device)
-        key = (self._hub_key if self._hub_key != "injected" else _tensor_key(hub), L, bool(cfg),
-               tuple(style.flatten().tolist()), None if emo is None else tuple(emo.flatten().tolist()))
-        if key != self._prep_key:
+        key = (L, bool(cfg), tuple(style.flatten().tolist()), None if emo is None else tuple(emo.flatten().tolist()))
+        pk = self._prep_key
+        if not (pk is not None and pk[0].matches(hub) and pk[1] == key):
             B = hub.shape[0]
             st = style.reshape(-1, style.shape[-1])
             em = None if emo is None else emo.reshape(-1, emo.shape[-1])
             plan.prepare(hub, st if st.shape[0] == B else st[0], em if (em is None or em.shape[0] == B) else em[0], L=L, cfg=cfg)
-            self._prep_key = key
+            self._prep_key = (_TensorKey(hub), key)
         return plan
 
     def _forward(self, audio, t, vertice, style, emo=None):
@@ -220,7 +278,7 @@ class _FDMBase(ParamTree):
         hub = self.audio_features(audio)
         nf = min(hub.shape[1] // self.preset.pair, L)                 # models/fdm_vocaset.py:64-66
         plan = self.prepare(audio, nf, style, emo)
-        tt = int(t.flatten()[0]) if torch.is_tensor(t) else int(t)
+        tt = _scalar_t(t)
         x = vertice.reshape(vertice.shape[0], L, G * vertice.shape[2])[:, :nf].reshape(vertice.shape[0], nf * G, -1)
         return plan.denoise(x.contiguous().float(), tt)
 
@@ -284,8 +342,7 @@ class ClassifierFreeSampleModel(nn.Module):
         m = self.model
         L = x_noisy.shape[1] // m.preset.G
         plan = m.prepare(audio, L, id_one_hot, emotion_one_hot.reshape(-1, emotion_one_hot.shape[-1]), cfg=True)
-        tt = int(t.flatten()[0]) if torch.is_tensor(t) else int(t)
-        return plan.denoise(x_noisy.contiguous().float(), tt, cfg_scale=self.level)
+        return plan.denoise(x_noisy.contiguous().float(), _scalar_t(t), cfg_scale=self.level)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -325,16 +382,15 @@ class GaussianDiffusion(nn.Module):
 
     def q_sample(self, x_start, t, noise=None):
         """sqrt(abar_t) x0 + sqrt(1 - abar_t) eps (:729-735) through the fused scheduler kernel (all clips share t)."""
-        noise = torch.randn_like(x_start) if noise is None else noise
         if not x_start.is_cuda:
-            return self._extract(self.sqrt_alphas_cumprod, t, x_start.shape) * x_start + \
-                self._extract(self.sqrt_one_minus_alphas_cumprod, t, x_start.shape) * noise
+            raise FdmError("GaussianDiffusion.q_sample runs on the HIP path only: move the latents to the GPU")
+        noise = torch.randn_like(x_start) if noise is None else noise
         from . import ops
         x0 = x_start.float().contiguous()
         z = noise.float().contiguous()
         out = torch.empty_like(x0)
         zero = torch.zeros(self.num_timesteps, device=x0.device)
-        tt = t.flatten()[:1].to(torch.int32).contiguous()
+        tt = torch.tensor([_scalar_t(t)], dtype=torch.int32, device=x0.device)
         ops.sched_step(0, x0, z, out, x0.numel(), tseq=tt, c1=self.sqrt_alphas_cumprod, c2=self.sqrt_one_minus_alphas_cumprod,
                        sigma=zero, noise=z)
         return out
@@ -371,7 +427,7 @@ class GaussianDiffusion(nn.Module):
     def p_sample(self, x, t, audio, *cond, clip_denoised=False, noise=None):
         """One reverse step on the HIP path (denoiser + fused scheduler update)."""
         plan, scale = self._plan(audio, x.shape, cond)
-        tt = int(t.flatten()[0])
+        tt = _scalar_t(t)
         z = noise if noise is not None else torch.randn_like(x)
         return plan.sample_ddpm(x.float().contiguous(), [tt], noise=z.reshape(1, *x.shape), cfg_scale=scale, use_graph=False)
 
@@ -433,7 +489,7 @@ class VQAutoEncoder(ParamTree):
 
     def plan(self, device):
         if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
-            self._plan = VQPlan(self.preset, self.state_dict(), self._dtype, device)
+            self._plan = VQPlan(self.preset, self.state_dict(), _side_dtype(self._dtype), device)
             self._plan_stale = False
         return self._plan
 

@@ -8,11 +8,14 @@
  * return 0 on success or a negative error code (message via fdm_last_error()), never throw and
  * never synchronise the device.  Nothing here takes or returns a torch type.
  *
- * Two layers:
+ * Three layers:
  *   fdm_op_*    single-kernel operators (one launch on the given stream)
  *   fdm_prog_*  a recorded sequence of operators = one "step program", captured into a hipGraph and
  *               replayed T times with the diffusion timestep read from a device-side counter
- *   fdm_plan_*  the denoiser + scheduler plan (weights, workspaces, tables, step program)
+ *   fdm_plan_* / fdm_audio_prepare / fdm_denoise_step / fdm_sample_graph
+ *               the denoiser + scheduler of one model (weights by reference state-dict name, per-model and
+ *               per-clip tables, workspaces, the step program and its hipGraph): what FDM.__init__ / FDM.forward
+ *               and GaussianDiffusion.sample / ddim_sample do in the reference, behind plain pointers
  */
 #ifndef FDM_HIP_H
 #define FDM_HIP_H
@@ -75,6 +78,8 @@ typedef struct fdm_sched_args {
   unsigned long long seed; int clip0;
   int mode;                                                  /* 0 DDPM, 1 DDIM, 2 CFG mix only (x_out = mix) */
   long long x_out_t_lo_off;                                  /* split out_dtype: elements between the hi and lo planes of x_out_t */
+  const unsigned long long* seed_dev;                        /* optional device words {seed, clip0}: override `seed` / `clip0`, so a
+                                                                captured graph serves every seed / shard (no re-capture per call) */
 } fdm_sched_args;
 int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
 
@@ -277,6 +282,81 @@ int fdm_prog_set_lane(fdm_prog* p, int lane);
 /* Run every lane's ops eagerly n times (no hipGraph), each lane on its own internal stream fed by its own
  * host thread; joined into `stream` at the end. */
 int fdm_prog_run_lanes(fdm_prog* p, int n, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Plan layer.  A plan owns device copies of the model's weights, the tables derived from them,
+ * its workspaces and the recorded step program; the caller owns every tensor it passes in.  The only functions that
+ * allocate or synchronise are fdm_plan_create / _reserve / _commit / _tune / _destroy and the first fdm_sample_graph /
+ * fdm_denoise_step call of a program shape (graph instantiation).  A plan is not thread-safe; one plan per device/stream.
+ *
+ * Model geometry = the reference constructors' numbers (models/fdm_vocaset.py:9-51, models/fdm_vqvae_mead.py:9-53,
+ * models/fdm.py:10-48, models/utils/config.py): fdm_model_preset fills it for "vocaset", "mead", "biwi" (+ "_tiny" test twins). */
+typedef struct fdm_model_desc {
+  int d, n_head, n_layers, ffn;   /* feature_dim, heads, decoder layers, dim_feedforward (= 2 d) */
+  int G, c;                       /* latent vectors per frame, their width (G * c == d) */
+  int n_style, n_emo;             /* one-hot widths of style_embedd / emotion_embedd (0 = no emotion input) */
+  int audio_in, pair;             /* input width of audio_extract.0; audio-encoder frames folded per latent frame */
+  int pe_periodic, period;        /* PeriodicPositionalEncoding (period) or plain sinusoidal PE; ALiBi period */
+  int latent_mish, style_mish;    /* Mish after latent_encoder / style_embedd */
+  int max_len;                    /* init_biased_mask(max_seq_len = 600), models/fdm_vocaset.py:44 */
+} fdm_model_desc;
+int fdm_model_preset(const char* name, fdm_model_desc* out);
+
+typedef struct fdm_plan fdm_plan;
+/* Workspaces for up to B clips x L latent frames (x2 rows when cfg != 0: cond + uncond rows in one set of launches).
+ * dtype: FDM_F32 | FDM_BF16 | FDM_F16X3 | FDM_BF16X3 = the arithmetic mode of the step program. */
+int fdm_plan_create(const fdm_model_desc* desc, int B, int L, int cfg, int dtype, fdm_plan** out);
+int fdm_plan_reserve(fdm_plan* p, int B, int L, int cfg);           /* grow the workspaces (allocates; drops recorded programs) */
+int fdm_plan_destroy(fdm_plan* p);
+/* One fp32 tensor of the reference state dict (FDM.state_dict() names, e.g. "transformer_decoder.layers.0.linear1.weight",
+ * "latent_decoder.bias", optional buffer "PE.pe"), n elements at ptr (host or device memory); copied into the plan.
+ * Optional schedule overrides "sched.c1", "sched.c2", "sched.sigma", "sched.sra", "sched.srm1" ([1000] fp32 each: the
+ * caller's own q_posterior / predict_noise tables; default = fdm_schedule_host's). */
+int fdm_plan_set_weights(fdm_plan* p, const char* name, const float* ptr, long long n, void* stream);
+/* Per-model tables: operand-kind weight copies, tau[t] = Mish(W_t[:, t] + b_t), folded cross-attention time tables
+ * TT_l = Wo_l Wv_l tau, LayerNorm folds of the bf16 program.  Called implicitly by fdm_audio_prepare. */
+int fdm_plan_commit(fdm_plan* p, void* stream);
+/* Once per batch of clips (the hoisted, step-invariant part of FDM.forward, models/fdm_vocaset.py:59-84):
+ * hub [B, N, fw] audio-encoder features (fw * pair == audio_in), style [B, n_style], emo [B, n_emo] or NULL, device fp32.
+ * L <= N / pair latent frames.  Builds AF = audio_extract(hub), the per-layer tables C1_l = Wo_l (Wv_l AF + bv_l) + bo_l
+ * and E0 = PE + style (+ emotion; the uncond rows of a CFG plan use emotion_embedd's bias only).                        */
+int fdm_audio_prepare(fdm_plan* p, const float* hub, int B, int N, int fw, const float* style, const float* emo,
+                      int L, int cfg, void* stream);
+/* One FDM.forward (models/fdm_vocaset.py:54-91): x_t [B, L*G, c] -> x0_hat [B, L*G, c], CFG-mixed
+ * (x0u + cfg_scale (x0 - x0u), utiles/classifierfree.py:20-21) when prepared with cfg.  x0_uncond (optional) receives
+ * the unconditional rows.  Eager launches of the recorded step program. */
+int fdm_denoise_step(fdm_plan* p, const float* x_t, int t, float cfg_scale, float* x0_hat, float* x0_uncond, void* stream);
+/* GaussianDiffusion.p_sample_loop / ddim_sample (diffusion_BIWI_encoder_decoder.py:649-710, diffusion_mead_encoder_decoder.py:
+ * 649-667): the step program (denoiser + fused scheduler update) replayed n_steps times as a hipGraph, the timestep read
+ * from a device-side counter; graph_steps (default 10) diffusion steps are captured per graph launch. */
+typedef struct fdm_sample_args {
+  int kind;                       /* 0 = DDPM over t_list, 1 = DDIM (eta = 0) with `ddim_steps` (the dead last pair is skipped) */
+  const float* x_T; float* out;   /* [B, L*G, c] device fp32 (may alias) */
+  const int* t_list; int n_steps; /* DDPM: host array of timesteps, descending */
+  int ddim_steps;
+  const float* noise;             /* DDPM: [n_steps, B, L*G, c] device fp32 injected z, or NULL: Philox(seed, clip0 + b, step) */
+  unsigned long long seed; int clip0;
+  float cfg_scale;
+  int eager;                      /* != 0: launch the recorded ops directly instead of replaying the graph (bit-identical) */
+  float* record;                  /* optional [n_steps, B, L*G, c]: the latent after every step */
+  int graph_steps;                /* diffusion steps per graph launch; 0 = default */
+} fdm_sample_args;
+int fdm_sample_graph(fdm_plan* p, const fdm_sample_args* a, void* stream);
+/* Plan-time tuning of the GEMM output tiles at the prepared shape (times candidates per call site; changes speed only). */
+int fdm_plan_tune(fdm_plan* p, void* stream);
+/* Introspection / experiments: integer properties by name -- "launches_per_step", "graph_launches" (host graph launches of
+ * the last fdm_sample_graph), "fuse_ln3", "rows", "tile.<call site>" (qkv, out, ffn1, ffn2, enc, dec, ...). */
+int fdm_plan_get(fdm_plan* p, const char* key, long long* out);
+int fdm_plan_set(fdm_plan* p, const char* key, long long value);    /* "tile.<call site>" (drops recorded programs), "tune" (0 = off) */
+
+/* Host-side tables (no device needed): the 12 GaussianDiffusion buffers in registration order, T floats each
+ * (diffusion_BIWI_encoder_decoder.py:565-603: cosine schedule in fp64, fp32 cast); DDIM pairs and per-pair coefficients
+ * (:684-708, eta = 0; returns the number of live pairs, the dead (t, -1) pair excluded); get_slopes (models/fdm_vocaset.py:96-106);
+ * the positional tables (:150-184). */
+int fdm_schedule_host(int T, float* out12);
+int fdm_ddim_schedule_host(int steps, int T, int* t, int* t_next, float* sqrt_an, float* c_n);
+int fdm_alibi_slopes_host(int n_head, float* out);
+int fdm_pe_table_host(int d, int periodic, int period, int rows, float* out);
 
 #ifdef __cplusplus
 }

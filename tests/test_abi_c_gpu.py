@@ -21,3 +21,43 @@ def test_c_program_links_and_runs_against_the_library(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_smoke ok" in r.stdout
+
+
+def _write_records(path, recs):
+    import struct
+    import numpy as np
+    with open(path, "wb") as f:
+        for name, arr in recs.items():
+            a = np.ascontiguousarray(np.asarray(arr, dtype=np.float32)).reshape(-1)
+            nb = name.encode()
+            f.write(struct.pack("<I", len(nb)) + nb + struct.pack("<Q", a.size) + a.tobytes())
+
+
+@pytest.mark.parametrize("dtype", [0, 2])          # FDM_F32, FDM_F16X3: the two modes inside the 1e-4 contract
+def test_plan_layer_samples_a_clip_without_python(tmp_path, golden, dtype):
+    """tests/abi_c/plan_smoke.cpp: model + case from a flat file -> fdm_plan_* / fdm_audio_prepare / fdm_sample_graph ->
+    the reference's own chain outputs (tests/golden/chains_vocaset_tiny.npz) at 1e-4.  Python only writes the input file
+    (seeded weights by reference state-dict name) and starts the process."""
+    import numpy as np
+    from fdm_amd import _lib
+    from oracle import weights as W
+    preset = "vocaset_tiny"
+    g = golden(f"chains_{preset}")
+    L = int(g["L"])
+    inp = W.synth_inputs(preset, 1, L, seed=7)
+    recs = {"w:" + k: v.numpy() for k, v in W.make_fdm_weights(preset).items()}
+    recs.update(preset=np.frombuffer(preset.encode(), dtype=np.uint8), hub=inp["hub"].numpy(), style=inp["style"].numpy(),
+                x_T=inp["x"].numpy(), noise=g["ddpm_lo_noise"], t_list=g["ddpm_lo_t"], expected_steps=g["ddpm_lo_steps"],
+                expected_ddim3=g["ddim_3_final"], meta=[L, inp["hub"].shape[1], inp["hub"].shape[2], len(g["ddpm_lo_t"])])
+    case = str(tmp_path / "case.bin")
+    _write_records(case, recs)
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = str(tmp_path / "plan_smoke")
+    cmd = [hipcc, "-O2", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "abi_c", "plan_smoke.cpp"),
+           "-I", os.path.join(ROOT, "include"), "-L", libdir, "-lfdm_hip", "-Wl,-rpath," + libdir, "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe, case, str(dtype)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "plan_smoke ok" in r.stdout
+    print(r.stdout.strip())

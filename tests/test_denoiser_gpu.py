@@ -110,9 +110,9 @@ def test_cfg_two_pass_mix_vs_golden(golden, dtype):
     L, t = int(g["L"]), int(g["t"])
     inp = W.synth_inputs("mead", 1, L, seed=55)
     plan.prepare(inp["hub"], inp["style"], inp["emo"], L=L, cfg=True)
-    out = plan.denoise(inp["x"].to(DEV), t, cfg_scale=2.5)
+    out, unc = plan.denoise(inp["x"].to(DEV), t, cfg_scale=2.5, return_uncond=True)
     assert mad(out[0], g["mix"]) < TOL32
-    assert mad(plan.ws["x0"][plan.Mc:plan.Rc].reshape(-1, 64), g["uncond"]) < TOL32
+    assert mad(unc[0], g["uncond"]) < TOL32
 
 
 @pytest.mark.parametrize("preset,dtype", [("vocaset", F32), ("mead", F32), ("vocaset", BF16), ("vocaset", F16X3), ("mead", F16X3)])
@@ -257,30 +257,32 @@ def test_full_size_cfg2_chain_properties():
 
 @pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
 def test_gemm_tile_choice_changes_speed_not_results(dtype, monkeypatch):
-    """Plan-time tile tuning (DenoiserPlan._tune_tiles): every output tile accumulates k in the same order, so forcing
-    any tile at every tuned call site gives bit-identical latents; FDM_TUNE=0 (library heuristic) likewise."""
+    """Plan-time tile tuning (fdm_plan_tune): every output tile accumulates k in the same order, so forcing any tile at
+    every tuned call site gives bit-identical latents; FDM_TUNE=0 (library heuristic) likewise."""
     from fdm_amd._lib import TILE_64x64, TILE_64x64_S3, TILE_128x64_S3, TILE_96x128, TILE_64x64_S2, TILE_32x64_S3, TILE_128x64, TILE_128x128, TILE_256x128
+    from fdm_amd.denoiser import TILE_SITES
     L, t = 70, 432
     inp = W.synth_inputs("vocaset", 2, L, seed=5)
     plan, _ = plan_for("vocaset", dtype)
     plan.prepare(inp["hub"], inp["style"], L=L)
-    plan._tile_cache = {}
-    plan._tune_tiles()                 # forced (sampling calls tune lazily, once a shape has run 2000 steps)
-    assert all(0 <= v <= 9 for v in plan.tiles.values())
-    plan.tiles = {k: 0 for k in ("enc", "qkv", "qkv_ln", "out", "out_ln", "ffn1", "ffn2", "ffn2_stat", "dec", "dec_ln")}
+    plan.set("untune", 1)
+    plan.tune()                        # forced (sampling calls tune lazily, once a shape has run 2000 steps)
+    assert plan.get("tuned") == 1 and all(0 <= v <= 9 for v in plan.tiles.values())
+    for k in TILE_SITES:
+        plan.set("tile." + k, 0)
     base = plan.denoise(inp["x"].to(DEV), t).clone()
     for tile in (TILE_64x64, TILE_64x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_128x64, TILE_128x64_S3, TILE_128x128, TILE_96x128, TILE_256x128):
-        plan.tiles = {k: tile for k in plan.tiles}
-        plan._progs = {}
+        for k in TILE_SITES:
+            plan.set("tile." + k, tile)
         assert torch.equal(plan.denoise(inp["x"].to(DEV), t), base), f"tile {tile}"
     monkeypatch.setenv("FDM_TUNE", "0")
-    plan._tile_cache = {}
+    plan.set("untune", 1)
     plan.prepare(inp["hub"], inp["style"], L=L)
-    plan._tune_tiles()
-    assert plan.tiles == {}
+    plan.tune()
+    assert plan.get("tuned") == 0 and not any(plan.tiles.values())
     assert torch.equal(plan.denoise(inp["x"].to(DEV), t), base)
     monkeypatch.delenv("FDM_TUNE")
-    plan._tile_cache = {}
+    plan.set("untune", 1)
 
 
 @pytest.mark.parametrize("preset,L", [("vocaset", 498), ("mead", 300), ("vocaset", 600)])
@@ -305,13 +307,13 @@ def test_full_length_mead_cfg_chain_properties():
     ts = list(range(999, 879, -1))                # 120 steps
     plan, _ = plan_for("mead", F32)
     plan.prepare(inp["hub"], inp["style"], inp["emo"], L=L, cfg=True)
-    plan._tune_tiles()                            # forced: the B = 2 and B = 1 plans below run with their own tuned tiles
+    plan.tune()                            # forced: the B = 2 and B = 1 plans below run with their own tuned tiles
     xT = inp["x"].to(DEV)
     a = plan.sample_ddpm(xT, ts, seed=9, cfg_scale=2.5)
     assert torch.equal(a, plan.sample_ddpm(xT, ts, seed=9, cfg_scale=2.5)) and torch.isfinite(a).all()
     assert torch.equal(plan.sample_ddpm(xT, ts[:30], seed=9, cfg_scale=2.5, use_graph=False),
                        plan.sample_ddpm(xT, ts[:30], seed=9, cfg_scale=2.5, use_graph=True))
     plan.prepare(inp["hub"][1:], inp["style"][1:], inp["emo"][1:], L=L, cfg=True)
-    plan._tune_tiles()
+    plan.tune()
     one = plan.sample_ddpm(xT[1:], ts, seed=9, clip0=1, cfg_scale=2.5)
     assert torch.equal(one[0], a[1]), "clip result depends on the batch it was sampled in"

@@ -367,6 +367,7 @@ def test_program_record_graph_replay():
     n = 4096
     x = torch.zeros(n, device=DEV)
     one = torch.ones(n, device=DEV)
+    nz = torch.ones(10, n, device=DEV)          # injected noise is indexed [step k][element]
     tab = torch.arange(1000, dtype=torch.float32, device=DEV)
     zero = torch.zeros(1000, device=DEV)
     onev = torch.ones(1000, device=DEV)
@@ -375,7 +376,7 @@ def test_program_record_graph_replay():
     prog = ops.Program()
     with prog:
         # x <- tab[t] * 1 + 1 * x, t = tseq[step]; step += 1
-        ops.sched_step(0, one, x, x, n, tseq=tseq, step=step, advance=1, c1=tab, c2=onev, sigma=zero, noise=one)
+        ops.sched_step(0, one, x, x, n, tseq=tseq, step=step, advance=1, c1=tab, c2=onev, sigma=zero, noise=nz)
     assert prog.num_ops == 1
     s = torch.cuda.Stream()
     with torch.cuda.stream(s):
