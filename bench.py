@@ -119,6 +119,8 @@ def main():
                          "operands, three 16-bit MFMA passes) meet the 1e-4 contract; bf16x3 is kept for comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=0, help="profiling only: shorten the diffusion chain to this many steps")
+    ap.add_argument("--batch", type=int, default=0, help="tests only: clips per GPU instead of the configuration's")
+    ap.add_argument("--dump", default="", help="tests only: rank 0 saves the gathered output of the last call to this .npy file")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +150,8 @@ def main():
     preset, B, L, T, sampler, cfg = CONFIGS[a.config]
     if a.profile_steps:
         T = a.profile_steps
+    if a.batch:
+        B = a.batch
     p = presets.get(preset)
     dt = DTYPE_NAMES[a.dtype]
     plan = DenoiserPlan(preset, W.make_fdm_weights(preset), dt, dev)
@@ -214,6 +218,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt[0])
     assert torch.isfinite(out).all()
+    if a.dump and rank == 0:
+        import numpy as np
+        np.save(a.dump, out.float().cpu().numpy())
 
     if rank == 0:
         n_launch = a.steps * (T if sampler == "ddpm" else T - 1)
@@ -240,6 +247,9 @@ def main():
                                       if e2e else "synthetic audio-encoder features, Philox noise"), "global_batch": B * world,
                        "latent_frames": L, "diffusion_steps": T, "parallelism": f"clip-shard x{world}"},
             "diffusion_steps_per_s": round(n_launch / (ev_ms * 1e-3), 1),
+            "kernel_launches_per_diffusion_step": plan.get("launches_per_step"),
+            "host_graph_launches_per_sample": plan.get("graph_launches"),
+            "gemm_tiles": {k: v for k, v in plan.tiles.items() if v},      # plan-time choice per call site (FDM_TILE_*; others: heuristic)
             "roofline": {"bound": "mfma", "kernel": "denoiser step graph (one diffusion step, all kernels)",
                          "achieved": round(ach, 2), "peak": PEAK[a.dtype], "unit": "TFLOP/s",
                          "frac": round(ach / PEAK[a.dtype], 4), "traffic": traffic,

@@ -710,6 +710,19 @@ int time_prog(fdm_prog* prog, int warm, int reps, hipStream_t s, float* ms) {
   return rc;
 }
 
+void apply_tile_override(fdm_plan* P) {      // FDM_TILE_OVERRIDE="qkv_ln=5,ffn1=3": force call sites (experiments, pinned profiles)
+  const char* ov = getenv("FDM_TILE_OVERRIDE");
+  if (!ov) return;
+  const std::string sov(ov);
+  size_t pos = 0;
+  while (pos < sov.size()) {
+    const size_t comma = sov.find(',', pos), eq = sov.find('=', pos);
+    const size_t end = comma == std::string::npos ? sov.size() : comma;
+    if (eq != std::string::npos && eq < end) P->tiles[sov.substr(pos, eq - pos)] = atoi(sov.substr(eq + 1, end - eq - 1).c_str());
+    pos = end + 1;
+  }
+}
+
 int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
   // Time the candidate output tiles of every GEMM call site of the step at this plan's shapes and keep the fastest.  Each
   // candidate runs the call site's per-layer instances (distinct weights, so they come from beyond L2 as they do inside the
@@ -717,7 +730,17 @@ int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
   // n_steps < 0 forces).  Every tile accumulates k in the same order, so the choice changes speed only, never results.
   const std::string key = shape_key(P);
   const char* env = getenv("FDM_TUNE");
-  if (!P->tune_enabled || (env && !strcmp(env, "0")) || P->tile_cache.count(key)) return FDM_OK;
+  if (P->tile_cache.count(key)) return FDM_OK;
+  if (!P->tune_enabled || (env && !strcmp(env, "0"))) {
+    // tuning off: the library heuristic, or the pinned set of FDM_TILE_OVERRIDE ("qkv=8,ffn1=2": reproducible profiles)
+    if (getenv("FDM_TILE_OVERRIDE") && n_steps < 0) {
+      FCK(drop_programs(P, stream));
+      P->tiles.clear();
+      apply_tile_override(P);
+      P->tile_cache[key] = P->tiles;
+    }
+    return FDM_OK;
+  }
   if (n_steps >= 0) {
     long long& seen = P->steps_seen[key];
     const long long before = seen;
@@ -811,21 +834,12 @@ int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
     if (t_t < 0.995f * t_h) keep = tuned;
     if (getenv("FDM_TUNE_VERBOSE")) {
       std::string desc;
-      for (auto& kv : tuned) desc += kv.first + "=" + std::to_string(kv.second) + " ";
+      for (auto& kv : tuned) desc += kv.first + "=" + std::to_string(kv.second) + ",";
       fprintf(stderr, "[fdm tune] rows=%d candidates: %s chain %.3f -> %.3f ms: %s\n", P->R, desc.c_str(), t_h / 4, t_t / 4, keep.empty() ? "rejected" : "kept");
     }
   }
   P->tiles = keep;
-  if (const char* ov = getenv("FDM_TILE_OVERRIDE")) {       // experiments: "qkv_ln=5,ffn1=3" forces call sites after the tuning
-    std::string sov(ov);
-    size_t pos = 0;
-    while (pos < sov.size()) {
-      const size_t comma = sov.find(',', pos), eq = sov.find('=', pos);
-      const size_t end = comma == std::string::npos ? sov.size() : comma;
-      if (eq != std::string::npos && eq < end) P->tiles[sov.substr(pos, eq - pos)] = atoi(sov.substr(eq + 1, end - eq - 1).c_str());
-      pos = end + 1;
-    }
-  }
+  apply_tile_override(P);
   P->tile_cache[key] = P->tiles;
   return FDM_OK;
 }

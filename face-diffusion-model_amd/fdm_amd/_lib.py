@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdm_hip.so")
+# FDM_LIB_PATH: load another build of the same library (the AddressSanitizer host build, csrc `make asan`)
+LIB_PATH = os.environ.get("FDM_LIB_PATH") or os.path.join(_HERE, "libfdm_hip.so")
 
 F32, BF16, F16X3, BF16X3 = 0, 1, 2, 3      # include/fdm_hip.h FDM_*: operand kinds (the last two are split plane pairs)
 DTYPE_NAMES = {"f32": F32, "bf16": BF16, "f16x3": F16X3, "bf16x3": BF16X3}

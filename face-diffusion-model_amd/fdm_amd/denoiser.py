@@ -156,12 +156,20 @@ class DenoiserPlan:
             record.extend(rec[i] for i in range(len(t_list)))
         return out
 
-    def sample_ddim(self, x_T, steps, cfg_scale=2.5, use_graph=True, graph_steps=0):
+    def sample_ddim(self, x_T, steps, cfg_scale=2.5, use_graph=True, graph_steps=0, record=None):
         """ddim_sample (eta = 0).  The last pair (t, -1) never updates the latent in the reference (:695-696), so its
-        denoiser call is skipped: exact."""
+        denoiser call is skipped: exact.  record (a list) receives the latent after every live pair."""
         a = SampleArgs()
         a.kind, a.ddim_steps, a.cfg_scale, a.eager, a.graph_steps = 1, int(steps), float(cfg_scale), int(not use_graph), int(graph_steps)
-        return self._sample(a, x_T)
+        rec = None
+        if record is not None:
+            n_live = sum(1 for pr in schedule.ddim_time_pairs(int(steps)) if pr[1] >= 0)
+            rec = torch.empty(max(n_live, 1), *x_T.shape, device=self.device)
+            a.record = rec.data_ptr()
+        out = self._sample(a, x_T)
+        if rec is not None:
+            record.extend(rec[i] for i in range(n_live))
+        return out
 
     # ------------------------------------------------------------------------------------------
     def tune(self):

@@ -61,3 +61,41 @@ def test_plan_layer_samples_a_clip_without_python(tmp_path, golden, dtype):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "plan_smoke ok" in r.stdout
     print(r.stdout.strip())
+
+
+def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
+    """The N > 1 path end to end without an 8-GPU node: `bench.py --gpus 2` as two fresh processes (gloo backend, both ranks
+    on this box's one GPU, the launch contract's RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment), against the
+    single-process run of the same global batch: the gathered latents agree bit for bit and rank 0 prints one JSON line
+    with n_gpus = 2.  (The RCCL branch itself needs a multi-GPU node: unmeasured until a SCALE record exists.)"""
+    import json
+    import socket
+    import sys
+    import numpy as np
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already initialised the GPU: child launches must start from a process that has not")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    bench = os.path.join(ROOT, "bench.py")
+    common = [sys.executable, bench, "--config", "cfg1", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--dtype", "f32"]
+    one = str(tmp_path / "one.npy")
+    r = subprocess.run(common + ["--gpus", "1", "--batch", "2", "--dump", one], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    two = str(tmp_path / "two.npy")
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FDM_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(common + ["--gpus", "2", "--batch", "1", "--dump", two], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[0] + o[1] for o in outs)
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 2
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape == (2, 1600, 64) and np.array_equal(a, b)

@@ -82,3 +82,39 @@ def test_product_never_imports_oracle():
             if f.endswith(".py") or f.endswith(".hip") or f.endswith(".hpp"):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, os.path.join(dp, f)
+
+
+def test_program_recording_and_split_validation_without_device():
+    """fdm_prog_* records validated launches without touching a device: record, count, destroy (also the part of the host
+    layer the AddressSanitizer build exercises, tools/run_asan_tests.sh); split-operand arguments are validated."""
+    from fdm_amd import _lib
+    l = _lib.lib()
+    h = C.c_void_p()
+    assert l.fdm_prog_create(C.byref(h)) == 0
+    assert l.fdm_prog_begin(h) == 0
+    assert l.fdm_prog_begin(h) == -4                       # already recording on this thread
+    a = _lib.GemmArgs()
+    a.A, a.W, a.M, a.N, a.K, a.dtype, a.lda, a.ldw, a.out_f32, a.ldo_f32, a.ldr, a.ldo_t = 16, 16, 64, 64, 64, _lib.BF16, 64, 64, 16, 64, 64, 64
+    for _ in range(5):
+        assert l.fdm_op_gemm(C.byref(a), None) == 0        # recorded, not launched
+    a.dtype = _lib.F16X3
+    assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"a_lo_off" in l.fdm_last_error()
+    a.a_lo_off = a.w_lo_off = 4096
+    a.out_t = 16
+    assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"out_t_lo_off" in l.fdm_last_error()
+    a.out_t_lo_off = 4096
+    assert l.fdm_op_gemm(C.byref(a), None) == 0
+    assert l.fdm_op_cast(16, 16, 128, _lib.F16X3, None) == 0
+    assert l.fdm_op_cast(16, 16, 128, 7, None) == -1
+    ln = _lib.LnArgs()
+    ln.x, ln.gamma, ln.beta, ln.M, ln.d, ln.y_t, ln.dtype = 16, 16, 16, 4, 256, 16, _lib.F16X3
+    assert l.fdm_op_layernorm(C.byref(ln), None) == -1 and b"y_t_lo_off" in l.fdm_last_error()
+    at = _lib.AttnArgs()
+    at.Q = at.Kp = at.Vp = at.O = 16
+    at.hd, at.B, at.H, at.L, at.Lpad, at.ldq, at.ldo, at.dtype, at.o_split = 64, 1, 1, 8, 32, 64, 64, _lib.BF16, _lib.F16X3
+    assert l.fdm_op_attention(C.byref(at), None) == -1 and b"o_split" in l.fdm_last_error()
+    assert l.fdm_prog_end(h) == 0
+    assert l.fdm_prog_num_ops(h) == 7
+    assert l.fdm_prog_replay(h, 1, None) == -4             # not instantiated
+    assert l.fdm_prog_destroy(h) == 0
+    assert l.fdm_plan_get(None, b"rows", C.byref(C.c_longlong())) == -1

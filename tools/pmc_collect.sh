@@ -1,0 +1,31 @@
+#!/bin/bash
+# Counter passes over one bench configuration (rocprofv3 --pmc, one pass per process: SQ 8 slots, TCC 4, and never together
+# with the trace domains gpurun refuses).  usage: pmc_collect.sh <tag> <bench args...>;  output: gpurun_out/pmc_<tag>/*.csv
+# The program goes directly after `--` (python3 bench.py ...; no wrappers: the profiler's library initialises the GPU first).
+TAG=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
+STEPS=${PMC_STEPS:-30}
+cd /tmp; export TMPDIR=/tmp
+pass() { # name, counters...
+  local name=$1; shift
+  rm -rf $OUT/raw_$name
+  timeout 900 rocprofv3 --pmc "$@" --output-format csv -d $OUT/raw_$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --profile-steps $STEPS $BENCH_ARGS > $OUT/$name.log 2>&1
+  local f=$(find $OUT/raw_$name -name "*counter_collection.csv" | head -1)
+  if [ -n "$f" ]; then python3 $ROOT/tools/pmc_report.py reduce $f $OUT/$name.csv $STEPS $(grep -o '"kernel_launches_per_diffusion_step": [0-9]*' $OUT/$name.log | grep -o '[0-9]*$'); else echo "pass $name produced no counters"; tail -5 $OUT/$name.log; fi
+  rm -rf $OUT/raw_$name
+}
+BENCH_ARGS="$*"
+# durations first (kernel trace only)
+rm -rf $OUT/raw_trace
+timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/raw_trace -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --profile-steps $STEPS $BENCH_ARGS > $OUT/trace.log 2>&1
+f=$(find $OUT/raw_trace -name "*kernel_trace.csv" | head -1)
+python3 $ROOT/tools/pmc_report.py trace $f $OUT/trace.csv $STEPS $(grep -o '"kernel_launches_per_diffusion_step": [0-9]*' $OUT/trace.log | grep -o '[0-9]*$')
+rm -rf $OUT/raw_trace
+pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
+pass sq2 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_COEXEC_CYCLES
+pass fetch FETCH_SIZE TCC_HIT_sum
+pass write WRITE_SIZE TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum
+pass tcp TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
+pass ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_REQ_sum
+ls $OUT
