@@ -186,7 +186,7 @@ def main():
             out = plan.sample_ddpm(xT, ts, seed=1234, clip0=rank * B)
         else:
             out = plan.sample_ddim(xT, T)
-        if e2e:
+        if e2e and not a.profile_steps:      # (counter profiles of the step graph end with the chain)
             out = vq_plan.decode(vq_plan.quant(out * (1.5 / 1024))[0])
         return gather_clips(out, dist, sizes=[B] * world) if collect else out     # equal shards: no size exchange
 

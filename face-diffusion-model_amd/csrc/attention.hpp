@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
   if (bh >= p.B * p.H) return;
   const int b = bh / p.H, h = bh - b * p.H;
   const int q0 = (nqt - 1 - (rem >> 3)) * BQ;
-  __shared__ __attribute__((aligned(16))) float part_o[4][BQ][HD];
+  // (+4 floats per row: the merge writes below put 8 lanes on 8 consecutive rows at one column; without the pad they share
+  //  a bank group -- SQ_LDS_BANK_CONFLICT was 79 % of this kernel's LDS cycles)
+  __shared__ __attribute__((aligned(16))) float part_o[4][BQ][HD + 4];
   __shared__ float part_m[4][BQ], part_l[4][BQ];
 
   const T* Q = (const T*)p.Q + (size_t)b * L * p.ldq + (size_t)h * HD;

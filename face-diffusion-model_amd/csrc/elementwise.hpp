@@ -9,109 +9,74 @@
 namespace fdm {
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm: one wavefront per row, row held in registers (d = 256 * NV), two-pass statistics.
+// LayerNorm (+addends, +fused second LayerNorm, +activation): one workgroup of NV wavefronts per row (d = 256 * NV), one
+// float4 per thread, so every load of the row and of its addends is in flight at once; the statistics go wave_sum -> LDS
+// slot -> fixed-order sum (one barrier each, a slot per statistic: no reuse hazard).  One kernel for every row count, so
+// a clip's result never depends on the batch it is computed in.  (Round 1's wave-per-row form took 7.3 us at the step's
+// 800 rows against 5.4 us here; HEAVY = the activation may be a transcendental one -- GELU after HuBERT's conv LayerNorm --
+// and is templated out of the step's instances: the inlined libm forms were 90 % of that kernel's code.)
 // ------------------------------------------------------------------------------------------------
-// HEAVY: the output activation may be a transcendental one (GELU after HuBERT's conv LayerNorm).  The step's LayerNorms
-// are built without: the inlined libm activations x 16 elements per lane were 90 % of this kernel's code, and code size
-// is fixed cost per launch (profiles/README.md).
 template <typename T, int NV, bool HEAVY>
-__global__ __launch_bounds__(256) void ln_kernel(const fdm_ln_args p) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= p.M) return;
+__global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
+  __shared__ float red[4][NV];
   constexpr int d = 256 * NV;
-  const float* xr = p.x + (size_t)row * d;
-  const float* am = p.add_mat ? p.add_mat + (size_t)row * d : nullptr;
-  const float* at = nullptr;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x, col = tid * 4;
+  const bool two = p.gamma2 != nullptr;
+  f32x4 v = *(const f32x4*)(p.x + (size_t)row * d + col);
+  f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool has_e = p.add_mat || p.add_tab;
+  if (p.add_mat) e = *(const f32x4*)(p.add_mat + (size_t)row * d + col);
   if (p.add_tab) {
     const int k = p.tab_step ? *p.tab_step : 0;
     const int idx = p.tab_index ? p.tab_index[k] : k;
-    at = p.add_tab + (size_t)idx * d;
+    e += *(const f32x4*)(p.add_tab + (size_t)idx * d + col);
   }
-  f32x4 v[NV];
-  float s = 0.f;
-  const bool two = p.gamma2 != nullptr;
+  const f32x4 g1 = *(const f32x4*)(p.gamma + col), b1 = *(const f32x4*)(p.beta + col);
+  f32x4 g2 = g1, b2 = b1;
+  if (two) { g2 = *(const f32x4*)(p.gamma2 + col); b2 = *(const f32x4*)(p.beta2 + col); }
+  auto block_sum = [&](float x, int slot) {
+    x = wave_sum(x);
+    if (lane == 0) red[slot][wave] = x;
+    __syncthreads();
+    float t = 0.f;
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int col = (i * 64 + lane) * 4;
-    f32x4 a = *(const f32x4*)(xr + col);
-    if (!two && (am || at)) {
-      f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (am) e = *(const f32x4*)(am + col);
-      if (at) e += *(const f32x4*)(at + col);
-      a += e;
-    }
-    v[i] = a;
-    s += (a[0] + a[1]) + (a[2] + a[3]);
+    for (int w = 0; w < NV; ++w) t += red[slot][w];
+    return t;
+  };
+  if (!two && has_e) v += e;
+  float mean = block_sum((v[0] + v[1]) + (v[2] + v[3]), 0) * (1.f / d);
+  v -= mean;
+  float var = block_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), 1) * (1.f / d);
+  float rstd = 1.f / sqrtf(var + p.eps);
+  if (two) {       // h = LN1(x); stage 2 input = h + add_mat + add_tab[idx]
+    v = v * rstd * g1 + b1;
+    if (has_e) v += e;
+    mean = block_sum((v[0] + v[1]) + (v[2] + v[3]), 2) * (1.f / d);
+    v -= mean;
+    var = block_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), 3) * (1.f / d);
+    rstd = 1.f / sqrtf(var + p.eps);
   }
-  float mean = wave_sum(s) * (1.f / d);
-  float q = 0.f;
+  f32x4 y = v * rstd * g2 + b2;
+  if constexpr (HEAVY) {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    f32x4 c = v[i] - mean;
-    v[i] = c;
-    q += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+    for (int j = 0; j < 4; ++j) y[j] = act_apply(y[j], p.act);
+  } else if (p.act == ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
   }
-  if (two) {
-    // stage 1 -> h = LN1(x); stage 2 input = h + add_mat + add_tab[idx]
-    const float rstd1 = 1.f / sqrtf(wave_sum(q) * (1.f / d) + p.eps);
-    s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int col = (i * 64 + lane) * 4;
-      f32x4 a = v[i] * rstd1 * *(const f32x4*)(p.gamma + col) + *(const f32x4*)(p.beta + col);
-      if (am || at) {
-        f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (am) e = *(const f32x4*)(am + col);
-        if (at) e += *(const f32x4*)(at + col);
-        a += e;
-      }
-      v[i] = a;
-      s += (a[0] + a[1]) + (a[2] + a[3]);
-    }
-    mean = wave_sum(s) * (1.f / d);
-    q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      f32x4 c = v[i] - mean;
-      v[i] = c;
-      q += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
-    }
-  }
-  const float* gam = two ? p.gamma2 : p.gamma;
-  const float* bet = two ? p.beta2 : p.beta;
-  const float var = wave_sum(q) * (1.f / d);
-  const float rstd = 1.f / sqrtf(var + p.eps);
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int col = (i * 64 + lane) * 4;
-    f32x4 gm = *(const f32x4*)(gam + col);
-    f32x4 bt = *(const f32x4*)(bet + col);
-    f32x4 y = v[i] * rstd * gm + bt;
-    if constexpr (HEAVY) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = act_apply(y[j], p.act);
-    } else if (p.act == ACT_RELU) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
-    }
-    if (p.y_f32) *(f32x4*)(p.y_f32 + (size_t)row * d + col) = y;
-    if (p.y_t) store_opnd4<T>((typename Opnd<T>::E*)p.y_t + (size_t)row * d + col, p.y_t_lo_off, y);
-  }
+  if (p.y_f32) *(f32x4*)(p.y_f32 + (size_t)row * d + col) = y;
+  if (p.y_t) store_opnd4<T>((typename Opnd<T>::E*)p.y_t + (size_t)row * d + col, p.y_t_lo_off, y);
 }
 
 template <typename T, bool HEAVY>
 static hipError_t ln_launch_h(const fdm_ln_args& a, hipStream_t s) {
-  // rows (= waves) per workgroup.  FDM_LN_RPB=1|2 spreads few-hundred-row LayerNorms over more CUs; alternating A/B runs
-  // at cfg2 (800 rows) showed no difference beyond the +-1 % run-to-run spread of the boxes, so 4 stays.
-  static const int rpb_env = [] { const char* e = getenv("FDM_LN_RPB"); return e ? atoi(e) : 0; }();
-  const int rpb = (rpb_env == 1 || rpb_env == 2 || rpb_env == 4) ? rpb_env : 4;
-  dim3 grid((a.M + rpb - 1) / rpb), block(64 * rpb);
+  dim3 grid(a.M);
   switch (a.d) {
-    case 256: hipLaunchKernelGGL((ln_kernel<T, 1, HEAVY>), grid, block, 0, s, a); break;
-    case 512: hipLaunchKernelGGL((ln_kernel<T, 2, HEAVY>), grid, block, 0, s, a); break;
-    case 768: hipLaunchKernelGGL((ln_kernel<T, 3, HEAVY>), grid, block, 0, s, a); break;
-    case 1024: hipLaunchKernelGGL((ln_kernel<T, 4, HEAVY>), grid, block, 0, s, a); break;
+    case 256: hipLaunchKernelGGL((ln_row_kernel<T, 1, HEAVY>), grid, dim3(64), 0, s, a); break;
+    case 512: hipLaunchKernelGGL((ln_row_kernel<T, 2, HEAVY>), grid, dim3(128), 0, s, a); break;
+    case 768: hipLaunchKernelGGL((ln_row_kernel<T, 3, HEAVY>), grid, dim3(192), 0, s, a); break;
+    case 1024: hipLaunchKernelGGL((ln_row_kernel<T, 4, HEAVY>), grid, dim3(256), 0, s, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -1090,7 +1090,7 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
     return drop_programs(P, nullptr);
   }
   if (k.rfind("tile.", 0) == 0) {
-    if (value < 0 || value > FDM_TILE_32x64_S3) return fail(FDM_ERR_ARG, "plan_set: unknown tile %lld", value);
+    if (value < 0 || value > FDM_TILE_MAX) return fail(FDM_ERR_ARG, "plan_set: unknown tile %lld", value);
     P->tiles[k.substr(5)] = (int)value;
     P->tile_cache[shape_key(P)] = P->tiles;      // an explicit choice counts as tuned: sampling calls keep it
     return drop_programs(P, nullptr);

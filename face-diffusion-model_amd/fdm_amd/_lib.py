@@ -52,6 +52,10 @@ class SampleArgs(C.Structure):
                 ("seed", C.c_ulonglong), ("clip0", ci), ("cfg_scale", cf), ("eager", ci), ("record", vp), ("graph_steps", ci)]
 
 
+class VqDesc(C.Structure):
+    _fields_ = [(n, ci) for n in ("G", "c", "K", "n_books", "V3", "pre")]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("ldq", ll), ("Kp", vp), ("Vp", vp), ("Lpad", ci),
                 ("O", vp), ("ldo", ll), ("B", ci), ("H", ci), ("L", ci), ("hd", ci), ("dtype", ci),
@@ -111,6 +115,17 @@ SYMBOLS = {
     "fdm_plan_tune": (ci, [vp, vp]),
     "fdm_plan_get": (ci, [vp, C.c_char_p, C.POINTER(ll)]),
     "fdm_plan_set": (ci, [vp, C.c_char_p, ll]),
+    "fdm_hubert_create": (ci, [ci, ci, ci, C.POINTER(vp)]),
+    "fdm_hubert_set_weights": (ci, [vp, C.c_char_p, vp, ll, vp]),
+    "fdm_hubert_forward": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, C.POINTER(ci), vp]),
+    "fdm_hubert_frames": (ci, [ci]),
+    "fdm_hubert_destroy": (ci, [vp]),
+    "fdm_vq_create": (ci, [C.POINTER(VqDesc), ci, C.POINTER(vp)]),
+    "fdm_vq_set_weights": (ci, [vp, C.c_char_p, vp, ll, vp]),
+    "fdm_vq_quant": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
+    "fdm_vq_decode": (ci, [vp, vp, ci, ci, vp, vp]),
+    "fdm_vq_encode": (ci, [vp, vp, vp, ci, ci, vp, vp]),
+    "fdm_vq_destroy": (ci, [vp]),
     "fdm_schedule_host": (ci, [ci, vp]),
     "fdm_ddim_schedule_host": (ci, [ci, ci, vp, vp, vp, vp]),
     "fdm_alibi_slopes_host": (ci, [ci, vp]),

@@ -148,6 +148,11 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_128x64_S3 7  /* 128x64 with a 3-stage ring (two workgroups per CU) */
 #define FDM_TILE_64x64_S2 8   /* 64x64 with a 2-stage ring (four workgroups per CU) */
 #define FDM_TILE_32x64_S3 9   /* 32x64 on 4 waves, 3-stage ring: twice the workgroups of 64x64 for few-hundred-row GEMMs */
+#define FDM_TILE_64x64_K128_S3 10   /* 64x64, 128-deep k-tiles (256-B LDS rows: half the barriers per K), 3-stage ring (96 KB) */
+#define FDM_TILE_64x64_K128_S2 11   /* the same with a 2-stage ring (64 KB: two workgroups per CU) */
+#define FDM_TILE_128x64_K128_S2 12  /* 128x64, 128-deep k-tiles, 2-stage ring (96 KB) */
+#define FDM_TILE_64x64_W4 13        /* 64x64 on 4 waves (32x32 per wave), 4-stage ring (64 KB: two workgroups per CU) */
+#define FDM_TILE_MAX 13
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -348,6 +353,42 @@ int fdm_plan_tune(fdm_plan* p, void* stream);
  * the last fdm_sample_graph), "fuse_ln3", "rows", "tile.<call site>" (qkv, out, ffn1, ffn2, enc, dec, ...). */
 int fdm_plan_get(fdm_plan* p, const char* key, long long* out);
 int fdm_plan_set(fdm_plan* p, const char* key, long long value);    /* "tile.<call site>" (drops recorded programs), "tune" (0 = off) */
+
+/* ------------------------------------------------------------------------------------------
+ * Audio encoder (once per clip: it does not depend on (t, x_t), so the reference's per-step re-run, models/fdm_vocaset.py:59,
+ * is hoisted).  kind 0 = HuBERT-large (models/hubert.py:75-146: 7 x {Conv1d, LayerNorm(512), GELU}, even crop, projection,
+ * weight-normed grouped positional conv, 24 pre-LN layers, final LayerNorm); kind 1 = wav2vec2-base (models/wav2vec.py:
+ * 69-143: GroupNorm on conv 0 only, no conv bias, 12 post-LN layers) -- the BIWI denoiser's encoder.  n_layers 0 = the
+ * kind's depth.  Weights by transformers state-dict name ("feature_extractor.conv_layers.0.conv.weight", ...,
+ * "encoder.pos_conv_embed.conv.parametrizations.weight.original0|1" or torch-2.0's "...conv.weight_g|weight_v").
+ * forward: wav [B, n] processor-normalised fp32 -> out [B, N, D] fp32, *n_frames = N = fdm_hubert_frames(n) (the conv
+ * stack's length, even-cropped, :95-96).  frame_num > 0 keeps at most 2 * frame_num frames (:97-98); interp_in_fps /
+ * interp_out_fps > 0 resample the conv features (linear_interpolation, :62-69) to frame_num or int(T / in * out) frames
+ * instead of the even crop.  The caller sizes `out` for fdm_hubert_frames(n) rows per clip (or the interpolated count). */
+typedef struct fdm_audio_encoder fdm_audio_encoder;
+int fdm_hubert_create(int kind, int n_layers, int dtype, fdm_audio_encoder** out);
+int fdm_hubert_set_weights(fdm_audio_encoder* e, const char* name, const float* ptr, long long n, void* stream);
+int fdm_hubert_forward(fdm_audio_encoder* e, const float* wav, int B, int n_samples, int frame_num, int interp_in_fps, int interp_out_fps,
+                       float* out, int* n_frames, void* stream);
+int fdm_hubert_frames(int n_samples);
+int fdm_hubert_destroy(fdm_audio_encoder* e);
+
+/* ------------------------------------------------------------------------------------------
+ * (E)VQ-VAE: quantise, decode, encode (models/vq_vae_vocaset.py:23-43, models/vq_vae_emotion.py:9-41, models/vq_vae.py).
+ * Geometry from the reference's *_vq_vae_args (models/utils/config.py): G = face_quan_num, c = zquant_dim, K = 256 codes
+ * per book, n_books = n_embed / 256 (emotion-sliced codebook), V3 = in_dim; pre = decoder_linear_embedding_pre /
+ * encoder_linear_embedding_post present (3D-MEAD, BIWI).  Weights by reference state-dict name.
+ * quant:  z [B, R, c] (+ emotion one-hot [B, n_books]) -> z_q [B, c, R] (the reference's permuted output), idx [B*R] int64
+ * decode: z_q [B, c, L*G] -> vertex offsets [B, L, V3] (the caller adds the template; every clip gets pe[0], a20)
+ * encode: x [B, L, V3] (+ emotion one-hot [B, 7]) -> latent [B, L*G, c]                                                  */
+typedef struct fdm_vq_desc { int G, c, K, n_books, V3, pre; } fdm_vq_desc;
+typedef struct fdm_vq fdm_vq;
+int fdm_vq_create(const fdm_vq_desc* desc, int dtype, fdm_vq** out);
+int fdm_vq_set_weights(fdm_vq* v, const char* name, const float* ptr, long long n, void* stream);
+int fdm_vq_quant(fdm_vq* v, const float* z, const float* emo_one_hot, int B, int R, float* zq_bcl, long long* idx, void* stream);
+int fdm_vq_decode(fdm_vq* v, const float* zq_bcl, int B, int R, float* out, void* stream);
+int fdm_vq_encode(fdm_vq* v, const float* x, const float* emo_one_hot, int B, int L, float* latent, void* stream);
+int fdm_vq_destroy(fdm_vq* v);
 
 /* Host-side tables (no device needed): the 12 GaussianDiffusion buffers in registration order, T floats each
  * (diffusion_BIWI_encoder_decoder.py:565-603: cosine schedule in fp64, fp32 cast); DDIM pairs and per-pair coefficients

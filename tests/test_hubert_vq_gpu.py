@@ -201,3 +201,27 @@ def test_q_sample_and_forward_loss():
     ref = FO.fdm_forward(w, "vocaset", inp["hub"], t, xn_ref, inp["style"], None, folded=True)
     assert mad(x_recon, ref) < 1e-4
     assert abs(float(loss) - float(torch.nn.functional.mse_loss(inp["x"], ref))) < 1e-5
+
+
+def test_hubert_torch20_weight_norm_names_and_hf_prefixes():
+    """A torch-2.0 / HF *ForCTC checkpoint spells the positional conv's weight-norm tensors weight_g / weight_v and prefixes
+    every key with `hubert.`: both load and give the same features bit for bit."""
+    from fdm_amd.modules import HubertModel
+    w = W.make_hubert_weights(2)
+    wav = wav_for(1, 16400)
+    ref = HubertPlan(w, 2, F32, DEV).forward(wav)
+    old = {}
+    for k, v in w.items():
+        k = k.replace("conv.parametrizations.weight.original0", "conv.weight_g").replace("conv.parametrizations.weight.original1", "conv.weight_v")
+        old[k] = v
+    assert any(k.endswith("weight_g") for k in old)
+    assert torch.equal(HubertPlan(old, 2, F32, DEV).forward(wav), ref)
+    m = HubertModel(n_layers=2, seed=5)                       # different init: everything must come from the checkpoint
+    n = m.load_hf_state_dict({"hubert." + k: v for k, v in old.items()})
+    assert n == len(w)
+    assert torch.equal(m(wav.to(DEV)).last_hidden_state, ref)
+    from fdm_amd._lib import FdmError
+    bad = dict(old)
+    bad["feature_projection.projection.weight"] = torch.zeros(768, 512)
+    with pytest.raises(FdmError):
+        m.load_hf_state_dict(bad)                             # shape mismatches are reported, not skipped

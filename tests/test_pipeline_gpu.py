@@ -177,3 +177,29 @@ def test_plans_survive_callers_inference_mode_blocks():
     with torch.inference_mode():
         c = plan.sample_ddpm(inp["x"][:1].to("cuda:0"), [5, 4, 3, 2, 1, 0], seed=3)
     assert torch.equal(a, b) and torch.equal(c[0], a[0])
+
+
+def test_checkpoint_files_round_trip(tmp_path):
+    """stage-1 / stage-2 checkpoint FILES in the reference's layout ({'state_dict': ...} for the VQ-VAE, {'model': ...} for the
+    diffusion model, samples/sample_diffusion_vocaset.py:26,91-97) written with torch.save and loaded through
+    build_models(stage1=, stage2=): same state dicts, same animation bit for bit."""
+    import numpy as np
+    from fdm_amd import pipeline
+    d0, ae0 = pipeline.build_models("vocaset", device=DEV)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for prm in list(d0.parameters()) + list(ae0.parameters()):
+            if prm.dim() >= 2 and "audio_encoder" not in str(type(prm)):
+                prm.add_(torch.randn(prm.shape, generator=g) * 1e-3)
+    d0.denoise_fn._plan_stale = True
+    ae0._plan_stale = True
+    s1, s2 = str(tmp_path / "stage1.pth.tar"), str(tmp_path / "stage2.mpt")
+    torch.save({"state_dict": ae0.state_dict()}, s1)
+    torch.save({"model": d0.state_dict()}, s2)
+    d1, ae1 = pipeline.build_models("vocaset", device=DEV, stage1=s1, stage2=s2)
+    for a, b in ((d0.state_dict(), d1.state_dict()), (ae0.state_dict(), ae1.state_dict())):
+        assert a.keys() == b.keys() and all(torch.equal(a[k], b[k]) for k in a)
+    wav = pipeline.processor_normalize(np.sin(np.arange(16000) * 0.05).astype(np.float32), pad_seconds=0.2)
+    o0, _ = pipeline.animate(d0, ae0, wav, ddim_steps=5, seed=3, device=DEV)
+    o1, _ = pipeline.animate(d1, ae1, wav, ddim_steps=5, seed=3, device=DEV)
+    assert o0.shape[0] == 1 and torch.isfinite(o0).all() and torch.equal(o0, o1)

@@ -27,5 +27,6 @@ pass sq2 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 
 pass fetch FETCH_SIZE TCC_HIT_sum
 pass write WRITE_SIZE TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum
 pass tcp TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
-pass ea TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_REQ_sum
+HEAD=$(cd $ROOT && git rev-parse --short HEAD 2>/dev/null || echo unknown)
+python3 $ROOT/tools/pmc_report.py derive $OUT $OUT/summary.json "{\"tag\": \"$TAG\", \"bench_args\": \"$BENCH_ARGS\", \"tiles\": \"${FDM_TILE_OVERRIDE:-tuned per run}\", \"steps_profiled\": $STEPS}"
 ls $OUT
