@@ -28,20 +28,27 @@
 
 namespace fdm {
 
-// accurate expf on the fp32 (parity) path, hardware exp2 on the bf16 (throughput) path
+// accurate expf on the parity paths (fp32, split fp16), hardware exp2 on the bf16 (throughput) path
 // (bf16 callers pre-multiply the exponent by log2(e))
 template <typename T> __device__ __forceinline__ float fexp(float x) {
-  if constexpr (sizeof(T) == 4) return expf(x);
-  else return __builtin_amdgcn_exp2f(x);
+  if constexpr (std::is_same<T, bf16>::value) return __builtin_amdgcn_exp2f(x);
+  else return expf(x);
 }
 
+// T = float | bf16 | f16x3_t.  The split kind keeps Q, K and V as fp16 plane pairs (x = hi + lo / 2^11) and evaluates both
+// products in three 16-bit MFMA passes (hi.hi into the main accumulator, hi.lo + lo.hi into a second one, combined once per
+// key tile for the scores and once at the end for O); the probabilities are split the same way in registers.  fp32-class
+// results at a fifth of the fp32 kernel's MFMA time and half its key tiles.
 template <typename T, int HD, int QS>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
   // QS = 16-query sub-tiles per workgroup (1 or 2).  With QS = 2 every K / V^T fragment fetched from L2 feeds
   // two S^T and two O^T products: the kernel is bound by L2 -> register fragment traffic, which this halves.
-  constexpr int EPC = 16 / (int)sizeof(T);     // elements per 16 B fragment chunk
+  using E = typename Opnd<T>::E;
+  constexpr int NP = Opnd<T>::NP;
+  constexpr float SCL = Opnd<T>::SCALE;
+  constexpr int EPC = 16 / (int)sizeof(E);     // elements per 16 B fragment chunk
   constexpr int NKS = HD / (4 * EPC);          // MFMA k-steps over the head dim
-  constexpr int KT = 4 * EPC;                  // keys per tile (bf16 32, fp32 16)
+  constexpr int KT = 4 * EPC;                  // keys per tile (16-bit kinds 32, fp32 16)
   constexpr int NSUB = KT / 16;                // 16-key sub-tiles per tile
   constexpr int NC = HD / 16;                  // 16-row chunks of O^T
   constexpr int BQ = 16 * QS;
@@ -64,28 +71,35 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
   __shared__ __attribute__((aligned(16))) float part_o[4][BQ][HD + 4];
   __shared__ float part_m[4][BQ], part_l[4][BQ];
 
-  const T* Q = (const T*)p.Q + (size_t)b * L * p.ldq + (size_t)h * HD;
-  const T* Kp = (const T*)p.Kp + (size_t)(b * p.H + h) * HD * p.Lpad + (size_t)lane * EPC;
-  const T* Vp = (const T*)p.Vp + (size_t)(b * p.H + h) * HD * p.Lpad + (size_t)lane * EPC;
+  const E* Q = (const E*)p.Q + (size_t)b * L * p.ldq + (size_t)h * HD;
+  const E* Kp = (const E*)p.Kp + (size_t)(b * p.H + h) * HD * p.Lpad + (size_t)lane * EPC;
+  const E* Vp = (const E*)p.Vp + (size_t)(b * p.H + h) * HD * p.Lpad + (size_t)lane * EPC;
+  const size_t q_lo = NP == 2 ? (size_t)p.q_lo_off : 0, kv_lo = NP == 2 ? (size_t)p.kv_lo_off : 0;
 
   int qi[QS];                              // this lane's query index in each sub-tile
-  u32x4 qf[QS][NKS];
+  u32x4 qf[QS][NKS][NP];
   f32x4 o[QS][NC];
+  f32x4 ol[NP == 2 ? QS : 1][NP == 2 ? NC : 1];       // split kind: the two small products of O^T
   float m_run[QS], l_part[QS];
 #pragma unroll
   for (int u = 0; u < QS; ++u) {
     qi[u] = q0 + 16 * u + r16;
     const int qrow = min(qi[u], L - 1);
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) qf[u][ks] = *(const u32x4*)(Q + (size_t)qrow * p.ldq + (ks * 4 + g) * EPC);
+    for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) o[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int pl = 0; pl < NP; ++pl) qf[u][ks][pl] = *(const u32x4*)(Q + pl * q_lo + (size_t)qrow * p.ldq + (ks * 4 + g) * EPC);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      o[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (NP == 2) ol[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     m_run[u] = -INFINITY;
     l_part[u] = 0.f;
   }
 
   // bf16 path: softmax in the log2 domain (scale and slope carry log2(e); v_exp_f32 is a bare exp2)
-  constexpr float LG = (sizeof(T) == 2) ? 1.4426950408889634f : 1.f;
+  constexpr float LG = std::is_same<T, bf16>::value ? 1.4426950408889634f : 1.f;
   const float sc_mul = p.scale * LG;
   const float slope = p.slopes ? p.slopes[h] * LG : 0.f;
   const float inv_period = 1.f / (float)p.period;
@@ -100,16 +114,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
   for (int kt = wave; kt < ntiles; kt += 4) {
     const int kbase = kt * KT;
     // fragment-packed K / V: every operand fragment of this key tile is one contiguous 1 KB run
-    u32x4 kcur[NSUB][NKS];
+    u32x4 kcur[NSUB][NKS][NP];
 #pragma unroll
     for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        kcur[s][ks] = *(const u32x4*)(Kp + (size_t)((kt * NSUB + s) * NKS + ks) * (64 * EPC));
-      }
-    u32x4 vf[NC];
+      for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) vf[c] = *(const u32x4*)(Vp + (size_t)(kt * NC + c) * (64 * EPC));
+        for (int pl = 0; pl < NP; ++pl) kcur[s][ks][pl] = *(const u32x4*)(Kp + pl * kv_lo + (size_t)((kt * NSUB + s) * NKS + ks) * (64 * EPC));
+    u32x4 vf[NC][NP];
+    // split kind: the second half of V is requested after the scores (into the registers the K fragments free), which
+    // keeps the kernel at two waves per SIMD; its latency overlaps the softmax arithmetic
+    constexpr int NC_EARLY = (NP == 2) ? NC / 2 : NC;
+#pragma unroll
+    for (int c = 0; c < NC_EARLY; ++c)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) vf[c][pl] = *(const u32x4*)(Vp + pl * kv_lo + (size_t)(kt * NC + c) * (64 * EPC));
 #pragma unroll
     for (int u = 0; u < QS; ++u) {
       // a causal sub-tile whose last query precedes this key tile sees none of it (wave-uniform skip);
@@ -119,9 +138,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
 #pragma unroll
       for (int s = 0; s < NSUB; ++s) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NP == 1) {
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) Mma<T>::run(a, kcur[s][ks], qf[u][ks]);
+          for (int ks = 0; ks < NKS; ++ks) Mma<T>::run(a, kcur[s][ks][0], qf[u][ks][0]);
+        } else {
+          f32x4 al = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks) {
+            mma16<E>(a, kcur[s][ks][0], qf[u][ks][0]);
+            mma16<E>(al, kcur[s][ks][0], qf[u][ks][1]);
+            mma16<E>(al, kcur[s][ks][1], qf[u][ks][0]);
+          }
+          a += al * (1.f / SCL);
+        }
         sc[s] = a;
+      }
+      if constexpr (NP == 2 && QS == 1) {
+#pragma unroll
+        for (int c = NC_EARLY; c < NC; ++c)
+#pragma unroll
+          for (int pl = 0; pl < NP; ++pl) vf[c][pl] = *(const u32x4*)(Vp + pl * kv_lo + (size_t)(kt * NC + c) * (64 * EPC));
       }
       // scores -> scaled, biased, masked.  This lane holds keys kbase + goff + j with j = 4s + r (j < 8), so with
       // D = qi - (kbase + goff):  floor((qi - kj) / period) = floor(D / period) - (j > D mod period)   (period >= 8)
@@ -185,19 +221,41 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
       // the running maximum usually stops moving after the first tiles: skip the (AGPR round-trip) rescale then
       if (__any(alpha != 1.f)) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) o[u][c] *= alpha;
+        for (int c = 0; c < NC; ++c) {
+          o[u][c] *= alpha;
+          if constexpr (NP == 2) ol[u][c] *= alpha;
+        }
       }
-      // P^T fragment for the B port
-      u32x4 pf;
-      if constexpr (sizeof(T) == 2) {
-        bf16x8 pb = {(bf16)sc[0][0], (bf16)sc[0][1], (bf16)sc[0][2], (bf16)sc[0][3],
-                     (bf16)sc[NSUB - 1][0], (bf16)sc[NSUB - 1][1], (bf16)sc[NSUB - 1][2], (bf16)sc[NSUB - 1][3]};
-        pf = __builtin_bit_cast(u32x4, pb);
-      } else {
-        pf = __builtin_bit_cast(u32x4, sc[0]);
-      }
+      // P^T fragment(s) for the B port
+      if constexpr (NP == 1) {
+        u32x4 pf;
+        if constexpr (sizeof(E) == 2) {
+          bf16x8 pb = {(bf16)sc[0][0], (bf16)sc[0][1], (bf16)sc[0][2], (bf16)sc[0][3],
+                       (bf16)sc[NSUB - 1][0], (bf16)sc[NSUB - 1][1], (bf16)sc[NSUB - 1][2], (bf16)sc[NSUB - 1][3]};
+          pf = __builtin_bit_cast(u32x4, pb);
+        } else {
+          pf = __builtin_bit_cast(u32x4, sc[0]);
+        }
 #pragma unroll
-      for (int c = 0; c < NC; ++c) Mma<T>::run(o[u][c], vf[c], pf);
+        for (int c = 0; c < NC; ++c) Mma<T>::run(o[u][c], vf[c][0], pf);
+      } else {
+        typedef __attribute__((ext_vector_type(8))) E e8;
+        e8 ph, plo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = sc[j >> 2][j & 3];         // probabilities in [0, 1]: no clamp needed
+          const E hi = (E)x;
+          ph[j] = hi;
+          plo[j] = (E)((x - (float)hi) * SCL);
+        }
+        const u32x4 pfh = __builtin_bit_cast(u32x4, ph), pfl = __builtin_bit_cast(u32x4, plo);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          mma16<E>(o[u][c], vf[c][0], pfh);
+          mma16<E>(ol[u][c], vf[c][0], pfl);
+          mma16<E>(ol[u][c], vf[c][1], pfh);
+        }
+      }
     }
   }
 
@@ -208,7 +266,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
     l_tot = rows_sum(l_tot);
     if (g == 0) { part_m[wave][16 * u + r16] = m_run[u]; part_l[wave][16 * u + r16] = l_tot; }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) *(f32x4*)&part_o[wave][16 * u + r16][c * 16 + 4 * g] = o[u][c];
+    for (int c = 0; c < NC; ++c) {
+      f32x4 ov = o[u][c];
+      if constexpr (NP == 2) ov += ol[u][c] * (1.f / SCL);
+      *(f32x4*)&part_o[wave][16 * u + r16][c * 16 + 4 * g] = ov;
+    }
   }
   __syncthreads();
   {
@@ -232,13 +294,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) v += *(const f32x4*)&part_o[w][q][e0 + j] * sw[w];
         v *= inv;
-        if constexpr (sizeof(T) == 4) {
-          // fp32 attention feeding a split-operand GEMM (F16X3 / BF16X3 step programs): O is written as the plane pair
+        if constexpr (std::is_same<T, float>::value) {
+          // fp32 attention feeding a split-operand GEMM (BF16X3 step programs): O is written as the plane pair
           if (p.o_split == FDM_F16X3) store_opnd4<f16x3_t>((f16*)p.O + oo + j, p.o_lo_off, v);
           else if (p.o_split == FDM_BF16X3) store_opnd4<bf16x3_t>((bf16*)p.O + oo + j, p.o_lo_off, v);
           else *(f32x4*)((float*)p.O + oo + j) = v;
         } else {
-          store_opnd4<T>((T*)p.O + oo + j, 0, v);
+          store_opnd4<T>((E*)p.O + oo + j, p.o_lo_off, v);
         }
       }
     }
@@ -248,23 +310,31 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
 template <typename T, int HD>
 static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   // two query sub-tiles per workgroup once the sequence is long enough that halving the K / V traffic matters more
-  // than the number of workgroups; head_dim 256 keeps one (register budget)
+  // than the number of workgroups; head_dim 256 and the split kind keep one (register budget)
   static const int qs2 = getenv("FDM_ATTN_QS2") ? atoi(getenv("FDM_ATTN_QS2")) : 384;
   const int groups = (a.B * a.H + 7) / 8 * 8;        // (clip, head) pairs padded to whole XCD rounds
-  if (HD <= 128 && a.L >= qs2) {
-    dim3 grid((a.L + 31) / 32 * groups);
-    hipLaunchKernelGGL((attn_kernel<T, HD, (HD <= 128 ? 2 : 1)>), grid, dim3(256), 0, s, a);
-  } else {
-    dim3 grid((a.L + 15) / 16 * groups);
-    hipLaunchKernelGGL((attn_kernel<T, HD, 1>), grid, dim3(256), 0, s, a);
+  if constexpr (HD <= 128 && Opnd<T>::NP == 1) {
+    if (a.L >= qs2) {
+      dim3 grid((a.L + 31) / 32 * groups);
+      hipLaunchKernelGGL((attn_kernel<T, HD, 2>), grid, dim3(256), 0, s, a);
+      return;
+    }
   }
+  dim3 grid((a.L + 15) / 16 * groups);
+  hipLaunchKernelGGL((attn_kernel<T, HD, 1>), grid, dim3(256), 0, s, a);
 }
 
 template <typename T>
 static hipError_t attn_launch_dtype(const fdm_attn_args& a, hipStream_t s) {
-  if (a.hd == 256) attn_launch_t<T, 256>(a, s);
-  else if (a.hd == 128) attn_launch_t<T, 128>(a, s);
-  else attn_launch_t<T, 64>(a, s);
+  if constexpr (Opnd<T>::NP == 2) {       // split kind: head_dim 64 / 128 (256 does not fit the register file at two waves per SIMD)
+    if (a.hd == 128) attn_launch_t<T, 128>(a, s);
+    else if (a.hd == 64) attn_launch_t<T, 64>(a, s);
+    else return hipErrorInvalidValue;
+  } else {
+    if (a.hd == 256) attn_launch_t<T, 256>(a, s);
+    else if (a.hd == 128) attn_launch_t<T, 128>(a, s);
+    else attn_launch_t<T, 64>(a, s);
+  }
   return hipGetLastError();
 }
 

@@ -53,13 +53,13 @@ template <typename E> __device__ __forceinline__ void mma16(f32x4& acc, const u3
 //   f16x3_t : fp16 planes, 11 significant bits each -> 22 bits per operand, fp32-class results (SCALE = 2^11 keeps the
 //             residual plane in fp16's normal range; the two small products are summed in their own accumulator)
 //   bf16x3_t: bf16 planes, 8 bits each -> 16 bits per operand (kept for comparison: ~5e-5 per denoiser call)
-// E = element type in memory, NP = planes, KV = element type of the packed K / V outputs of a QKV projection in that
-// mode (split modes feed the fp32 attention kernel).
+// E = element type in memory, NP = planes, KV = operand kind of the packed K / V outputs of a QKV projection in that mode
+// (f16x3 feeds the split attention kernel plane pairs; bf16x3, the comparison mode, feeds the fp32 attention kernel).
 // ---------------------------------------------------------------------------------------------------
 struct f16x3_t {};
 struct bf16x3_t {};
 template <typename T> struct Opnd { using E = T; using KV = T; static constexpr int NP = 1; static constexpr float SCALE = 1.f; };
-template <> struct Opnd<f16x3_t> { using E = f16; using KV = float; static constexpr int NP = 2; static constexpr float SCALE = 2048.f; };
+template <> struct Opnd<f16x3_t> { using E = f16; using KV = f16x3_t; static constexpr int NP = 2; static constexpr float SCALE = 2048.f; };
 template <> struct Opnd<bf16x3_t> { using E = bf16; using KV = float; static constexpr int NP = 2; static constexpr float SCALE = 1.f; };
 
 // Store 4 consecutive fp32 values v as operand kind T at dst (split kinds: hi plane at dst, lo plane at dst + lo_off).

@@ -114,6 +114,7 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
     if (a->out_vp && (a->vp_col0 < 0 || a->vp_col0 % 4 || (a->N - a->vp_col0) % a->kv_hd)) return fail(FDM_ERR_SHAPE, "gemm: bad packed V column range");
     if (a->out_kp && (a->kp_col0 < 0 || a->kp_col0 % 4 || hi < a->kp_col0 || (hi - a->kp_col0) % a->kv_hd)) return fail(FDM_ERR_SHAPE, "gemm: bad packed K column range");
     if (!aligned16(a->out_kp) || !aligned16(a->out_vp)) return fail(FDM_ERR_ARG, "gemm: packed K/V buffers must be 16-byte aligned");
+    if (a->dtype == FDM_F16X3 && (a->kv_lo_off <= 0 || a->kv_lo_off % 8)) return fail(FDM_ERR_ARG, "gemm: split packed K/V outputs need kv_lo_off");
   }
   if (a->bias && !aligned16(a->bias)) return fail(FDM_ERR_ARG, "gemm: bias must be 16-byte aligned");
   if (a->ln_stat_in && (a->ln_nparts <= 0 || a->ln_dim <= 0)) return fail(FDM_ERR_ARG, "gemm: ln_stat_in needs ln_nparts and ln_dim");
@@ -142,10 +143,13 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream) {
   if (a->hd != 64 && a->hd != 128 && a->hd != 256) return fail(FDM_ERR_SHAPE, "attention: head_dim %d unsupported (64, 128, 256)", a->hd);
   if (a->B <= 0 || a->H <= 0 || a->L <= 0) return fail(FDM_ERR_SHAPE, "attention: B,H,L must be positive");
   if (a->Lpad < a->L || a->Lpad % 32) return fail(FDM_ERR_SHAPE, "attention: Lpad=%d must be a multiple of 32 >= L", a->Lpad);
-  if (a->dtype != FDM_F32 && a->dtype != FDM_BF16) return fail(FDM_ERR_ARG, "attention: bad dtype %d (split modes run the fp32 kernel with o_split)", a->dtype);
+  if (a->dtype != FDM_F32 && a->dtype != FDM_BF16 && a->dtype != FDM_F16X3) return fail(FDM_ERR_ARG, "attention: bad dtype %d (FDM_F32, FDM_BF16, FDM_F16X3)", a->dtype);
   if (a->o_split && (a->dtype != FDM_F32 || (a->o_split != FDM_F16X3 && a->o_split != FDM_BF16X3) || a->o_lo_off <= 0))
     return fail(FDM_ERR_ARG, "attention: o_split needs dtype FDM_F32, a split kind and o_lo_off");
-  const int epc = a->dtype == FDM_BF16 ? 8 : 4;
+  if (a->dtype == FDM_F16X3 && a->hd == 256) return fail(FDM_ERR_SHAPE, "attention: the split kind supports head_dim 64 and 128");
+  if (a->dtype == FDM_F16X3 && (a->q_lo_off <= 0 || a->kv_lo_off <= 0 || a->o_lo_off <= 0 || a->q_lo_off % 8 || a->kv_lo_off % 8 || a->o_lo_off % 4))
+    return fail(FDM_ERR_ARG, "attention: split operands need q_lo_off, kv_lo_off and o_lo_off");
+  const int epc = a->dtype == FDM_F32 ? 4 : 8;
   if (a->ldq % epc || a->ldo % 4 || !aligned16(a->Q) || !aligned16(a->Kp) || !aligned16(a->Vp) || !aligned16(a->O))
     return fail(FDM_ERR_ARG, "attention: operands need 16-byte aligned rows");
   if (a->slopes && a->period <= 0) return fail(FDM_ERR_ARG, "attention: period must be positive");

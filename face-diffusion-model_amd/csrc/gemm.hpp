@@ -27,7 +27,10 @@ namespace fdm {
 // producer side's per-fragment (sum, sum of squares) pairs [BN / 16][BM][2] live INSIDE the ring (free after the k
 // loop), behind the area of the transposed V tile.
 template <int BM, int BN> constexpr int gemm_ln_scratch_bytes() { return BM * 2 * 4; }
-template <typename T, int BM, int BN> constexpr int gemm_epi_ring_bytes() { return BM * BN * (int)sizeof(typename Opnd<T>::KV) + BM * 2 * (BN / 16) * 4; }
+template <typename T, int BM, int BN> constexpr int gemm_epi_ring_bytes() {
+  using KK = typename Opnd<T>::KV;
+  return BM * BN * (int)sizeof(typename Opnd<KK>::E) * Opnd<KK>::NP + BM * 2 * (BN / 16) * 4;
+}
 
 // Consumer side: mu / rstd of the block's rows from the producer's per-64-column partial sums (fixed order).
 template <int BM>
@@ -123,7 +126,9 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
                                               int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   using E = typename Opnd<T>::E;      // element type of out_t (split kinds: two planes of it)
-  using KV = typename Opnd<T>::KV;    // element type of the packed K / V outputs
+  using KK = typename Opnd<T>::KV;    // operand kind of the packed K / V outputs (a plane pair for f16x3)
+  using KV = typename Opnd<KK>::E;    // their element type
+  constexpr int KNP = Opnd<KK>::NP;
   const int M = p.M, N = p.N;
   // Whole-tile packed-V fast path: stage the tile transposed in LDS ([n][m], the ring is free after the k loop) and
   // store 16-byte runs of consecutive keys (one packed chunk each).  Needs the tile to lie entirely in the V columns
@@ -131,7 +136,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   constexpr int EPC_T = 16 / (int)sizeof(KV);
   const bool vt_tile = tile_lds && p.out_vp && n0 >= p.vp_col0 && n0 + BN <= N && (p.kv_L % EPC_T == 0);
   KV* tl = (KV*)tile_lds;
-  float* comb = tile_lds ? (float*)(tile_lds + BM * BN * (int)sizeof(KV)) : nullptr;
+  float* comb = tile_lds ? (float*)(tile_lds + BM * BN * (int)sizeof(KV) * KNP) : nullptr;
   const bool use_ln = rowstat && p.ln_stat_in;
   const bool do_stat = rowstat && comb && p.stat_out;
   if (vt_tile || do_stat) __syncthreads();      // every wave is done reading the last ring stage
@@ -199,13 +204,13 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         if (kv_mode == 2) {
           const int nl = wn * (BN / WN) + ni * 16 + 4 * g;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<KV>(v[j]);
+          for (int j = 0; j < 4; ++j) store_opnd1<KK>(tl + (nl + j) * BM + lrow, BM * BN, v[j]);
           continue;
         }
         if (kv_mode == 1) {
           const int cc = ncol + ni * 16 - kcol_lo;
           const int h = cc / p.kv_hd, e2 = cc - h * p.kv_hd;
-          store_opnd4<KV>(okp + (size_t)h * kv_blk + kp_offset<KV>(kv_l, e2, p.kv_hd), 0, v);
+          store_opnd4<KK>(okp + (size_t)h * kv_blk + kp_offset<KV>(kv_l, e2, p.kv_hd), p.kv_lo_off, v);
           continue;
         }
         if (o32) *(f32x4*)(o32 + ni * 16) = v;
@@ -274,7 +279,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       if (vt_tile) {
         const int nl = wn * (BN / WN) + ni * 16 + 4 * g;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tl[(nl + j) * BM + lrow] = from_f32<KV>(v[j]);
+        for (int j = 0; j < 4; ++j) store_opnd1<KK>(tl + (nl + j) * BM + lrow, BM * BN, v[j]);
         continue;
       }
       if (n >= kcol_lo && n < kcol_hi) {
@@ -282,7 +287,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         const int cc = n - kcol_lo;
         const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
         const int KH = (kcol_hi - kcol_lo) / p.kv_hd;
-        store_opnd4<KV>((KV*)p.out_kp + (size_t)(kv_b * KH + h) * kv_blk + kp_offset<KV>(kv_l, e, p.kv_hd), 0, v);
+        store_opnd4<KK>((KV*)p.out_kp + (size_t)(kv_b * KH + h) * kv_blk + kp_offset<KV>(kv_l, e, p.kv_hd), p.kv_lo_off, v);
         continue;
       }
       if (p.out_vp && n >= p.vp_col0) {
@@ -290,7 +295,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
           if (n + j >= N) break;
           const int cc = n + j - p.vp_col0;
           const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
-          ((KV*)p.out_vp)[(size_t)(kv_b * kv_H + h) * kv_blk + vp_offset<KV>(kv_l, e, p.kv_hd)] = from_f32<KV>(v[j]);
+          store_opnd1<KK>((KV*)p.out_vp + (size_t)(kv_b * kv_H + h) * kv_blk + vp_offset<KV>(kv_l, e, p.kv_hd), p.kv_lo_off, v[j]);
         }
         continue;
       }
@@ -325,7 +330,10 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
       const int b = m / p.kv_L, l = m - b * p.kv_L;
       const int cc = n0 + nl - p.vp_col0;
       const int h = cc / p.kv_hd, e = cc - h * p.kv_hd;
-      *(u32x4*)((KV*)p.out_vp + (size_t)(b * kv_H + h) * kv_blk + vp_offset<KV>(l, e, p.kv_hd)) = *(const u32x4*)(tl + nl * BM + ml);
+#pragma unroll
+      for (int pl = 0; pl < KNP; ++pl)
+        *(u32x4*)((KV*)p.out_vp + (size_t)pl * p.kv_lo_off + (size_t)(b * kv_H + h) * kv_blk + vp_offset<KV>(l, e, p.kv_hd)) =
+            *(const u32x4*)(tl + pl * BM * BN + nl * BM + ml);
     }
   }
   if (do_stat) {

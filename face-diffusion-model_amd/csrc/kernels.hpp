@@ -12,6 +12,7 @@ hipError_t gemm_launch_f16x3(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_bf16x3(const fdm_gemm_args& a, hipStream_t s);
 hipError_t attn_launch_f32(const fdm_attn_args& a, hipStream_t s);
 hipError_t attn_launch_bf16(const fdm_attn_args& a, hipStream_t s);
+hipError_t attn_launch_f16x3(const fdm_attn_args& a, hipStream_t s);
 hipError_t pack_kv_launch_f32(const void* K, long long ldk, const void* V, long long ldv, void* Kp, void* Vp, int B, int H, int L, int Lpad, int hd, hipStream_t s);
 hipError_t pack_kv_launch_bf16(const void* K, long long ldk, const void* V, long long ldv, void* Kp, void* Vp, int B, int H, int L, int Lpad, int hd, hipStream_t s);
 
@@ -24,6 +25,6 @@ inline hipError_t gemm_launch(const fdm_gemm_args& a, hipStream_t s) {
   }
 }
 inline hipError_t attn_launch(const fdm_attn_args& a, hipStream_t s) {
-  return a.dtype == FDM_BF16 ? attn_launch_bf16(a, s) : attn_launch_f32(a, s);
+  return a.dtype == FDM_BF16 ? attn_launch_bf16(a, s) : (a.dtype == FDM_F16X3 ? attn_launch_f16x3(a, s) : attn_launch_f32(a, s));
 }
 }  // namespace fdm

@@ -201,6 +201,8 @@ struct fdm_plan {
   float *h = nullptr, *h2 = nullptr, *x1 = nullptr, *x0 = nullptr, *x = nullptr, *x2 = nullptr, *stats = nullptr;
   Mat xt, ht, h2t, x2t, ctx, u;
   void *q = nullptr, *kp = nullptr, *vp = nullptr;
+  long long q_lo = 0, kv_lo = 0;             // FDM_F16X3: plane distances of q and of the packed K / V buffers
+  size_t kv_bytes = 0;
   float *AF = nullptr, *t1 = nullptr, *sty = nullptr, *em = nullptr, *emu = nullptr, *zeros = nullptr, *E0 = nullptr;
   std::vector<float*> C1;
   int* step = nullptr;                       // [device step counter, t of the current step]
@@ -469,10 +471,14 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   }
   // q: row-major queries; kp / vp: fragment-packed keys / values written by the QKV GEMM's epilogue (zeroed: pad keys must be
   // finite).  Split modes: attention runs in fp32, ctx returns as a plane pair.
-  const size_t ea = (is_split(P->dtype) || P->dtype == FDM_F32) ? 4 : 2;
+  // (FDM_F16X3: fp16 plane pairs, the same bytes as fp32; FDM_BF16X3: fp32, attention runs in fp32)
+  const size_t ea = P->dtype == FDM_BF16 ? 2 : 4;
   FCK(dalloc(P, &P->q, R * d * ea, true));
   FCK(dalloc(P, &P->kp, (size_t)B * repc * Lpad * d * ea, true));
   FCK(dalloc(P, &P->vp, (size_t)B * repc * Lpad * d * ea, true));
+  P->q_lo = (long long)(R * d);
+  P->kv_lo = (long long)((size_t)B * repc * Lpad * d);
+  P->kv_bytes = (size_t)B * repc * Lpad * d * ea;
   FCK(dalloc_mat(P, &P->ctx, R, d, true));
   FCK(dalloc_mat(P, &P->u, R, m.ffn, true));
   FCK(dalloc_t(P, &P->AF, M * d, true)); FCK(dalloc_t(P, &P->t1, M * d, true));
@@ -522,16 +528,19 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
       g = gemm_op(P, P->x2t, f->w, R, 3 * d, d);
       g.bias = f->bias; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.ln_colsum = f->colsum;
     }
-    if (split) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
-    else { g.out_t = P->q; g.ldo_t = d; }
+    const bool split_attn = P->dtype == FDM_F16X3;       // FDM_BF16X3 (comparison mode) keeps the fp32 attention kernel
+    if (split && !split_attn) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
+    else { g.out_t = P->q; g.ldo_t = d; g.out_t_lo_off = split_attn ? P->q_lo : 0; }
+    g.kv_lo_off = split_attn ? P->kv_lo : 0;
     g.out_kp = P->kp; g.kp_col0 = d; g.out_vp = P->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = P->Lpad; g.kv_hd = P->hd;
     FCK(plan_gemm(P, f ? "qkv_ln" : "qkv", g, stream));
     fdm_attn_args at;
     memset(&at, 0, sizeof(at));
     at.Q = P->q; at.ldq = d; at.Kp = P->kp; at.Vp = P->vp; at.Lpad = P->Lpad; at.O = P->ctx.p; at.ldo = d;
-    at.B = BB; at.H = m.n_head; at.L = L; at.hd = P->hd; at.dtype = split ? FDM_F32 : P->dtype;
+    at.B = BB; at.H = m.n_head; at.L = L; at.hd = P->hd; at.dtype = split_attn ? FDM_F16X3 : (split ? FDM_F32 : P->dtype);
     at.scale = 1.0f / std::sqrt((float)P->hd); at.causal = 1; at.slopes = P->slopes; at.period = m.period;
-    if (split) { at.o_split = P->dtype; at.o_lo_off = P->ctx.lo; }
+    if (split_attn) { at.q_lo_off = P->q_lo; at.kv_lo_off = P->kv_lo; at.o_lo_off = P->ctx.lo; }
+    else if (split) { at.o_split = P->dtype; at.o_lo_off = P->ctx.lo; }
     FCK(fdm_op_attention(&at, stream));
     FCK(need(P, lname(l, "self_attn.out_proj.bias"), d, &b));
     g = gemm_op(P, P->ctx, P->wt[lname(l, "self_attn.out_proj.weight")], R, d, d);
@@ -860,6 +869,7 @@ int fdm_plan_create(const fdm_model_desc* desc, int B, int L, int cfg, int dtype
   const int hd = m.d / m.n_head;
   if (hd != 64 && hd != 128 && hd != 256) return fail(FDM_ERR_SHAPE, "plan_create: head_dim %d unsupported (64, 128, 256)", hd);
   if (m.d != 256 && m.d != 512 && m.d != 768 && m.d != 1024) return fail(FDM_ERR_SHAPE, "plan_create: feature_dim %d unsupported (256, 512, 768, 1024)", m.d);
+  if (dtype == FDM_F16X3 && hd == 256) return fail(FDM_ERR_SHAPE, "plan_create: FDM_F16X3 supports head_dim 64 / 128 (split attention); use FDM_F32 for head_dim 256");
   if (B < 1 || L < 1 || L > m.max_len) return fail(FDM_ERR_SHAPE, "plan_create: B=%d, L=%d outside [1, .] x [1, %d] (models/fdm_vocaset.py:44)", B, L, m.max_len);
   if (!fdm_device_ok()) return fail(FDM_ERR_STATE, "plan_create: no gfx950 device visible (there is no CPU fallback)");
   fdm_plan* P = new (std::nothrow) fdm_plan();
@@ -923,9 +933,8 @@ int fdm_audio_prepare(fdm_plan* P, const float* hub, int B, int N, int fw, const
   const int d = m.d, M = B * L, rep = cfg ? 2 : 1;
   P->B = B; P->L = L; P->M = M; P->rep = rep; P->R = M * rep; P->cfg = cfg ? 1 : 0; P->Lpad = (L + 31) / 32 * 32;
   // pad keys of the packed K / V buffers must be finite: the layout depends on (L, Lpad), so clear them per shape
-  const size_t ea = P->dtype == FDM_BF16 ? 2 : 4;
-  HIPCK(hipMemsetAsync(P->kp, 0, (size_t)B * rep * P->Lpad * d * ea, s));
-  HIPCK(hipMemsetAsync(P->vp, 0, (size_t)B * rep * P->Lpad * d * ea, s));
+  HIPCK(hipMemsetAsync(P->kp, 0, P->kv_bytes, s));
+  HIPCK(hipMemsetAsync(P->vp, 0, P->kv_bytes, s));
   const float *w0 = nullptr, *b0 = nullptr, *w2 = nullptr, *b2 = nullptr;
   FCK(need(P, "audio_extract.0.weight", (long long)d * m.audio_in, &w0)); FCK(need(P, "audio_extract.0.bias", d, &b0));
   FCK(need(P, "audio_extract.2.weight", (long long)d * d, &w2)); FCK(need(P, "audio_extract.2.bias", d, &b2));

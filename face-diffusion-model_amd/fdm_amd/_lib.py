@@ -36,7 +36,7 @@ class GemmArgs(C.Structure):
                 ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
                 ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci),
                 ("sched_fuse", ci), ("sched", SchedArgs),
-                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll)]
+                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll)]
 
 
 TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -59,7 +59,7 @@ class VqDesc(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("ldq", ll), ("Kp", vp), ("Vp", vp), ("Lpad", ci),
                 ("O", vp), ("ldo", ll), ("B", ci), ("H", ci), ("L", ci), ("hd", ci), ("dtype", ci),
-                ("scale", cf), ("causal", ci), ("slopes", vp), ("period", ci), ("o_split", ci), ("o_lo_off", ll)]
+                ("scale", cf), ("causal", ci), ("slopes", vp), ("period", ci), ("o_split", ci), ("o_lo_off", ll), ("q_lo_off", ll), ("kv_lo_off", ll)]
 
 
 class LnArgs(C.Structure):

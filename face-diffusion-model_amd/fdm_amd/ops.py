@@ -96,6 +96,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     if code_of(W) != a.dtype:
         raise _lib.FdmError("gemm: A and W operand kinds differ")
     a.a_lo_off, a.w_lo_off, a.out_t_lo_off = _lo(A), _lo(W), _lo(out_t)
+    a.kv_lo_off = _lo(out_kp) or _lo(out_vp)
     a.bias, a.bias_batch_stride, a.act = _p(bias), bias_bs, act
     a.resid, a.ldr, a.resid_row_mod = _p(resid), (ldr if ldr is not None else N), resid_row_mod
     a.out_f32, a.ldo_f32 = _p(out_f32), (ldo_f32 if ldo_f32 is not None else N)
@@ -132,7 +133,9 @@ def attention(Q, Kp, Vp, O, *, B, H, L, hd, ldq, ldo, Lpad, scale, causal=False,
     a = AttnArgs()
     a.Q, a.ldq, a.Kp, a.Vp, a.Lpad = _p(Q), ldq, _p(Kp), _p(Vp), Lpad
     a.O, a.ldo, a.B, a.H, a.L, a.hd, a.dtype = _p(O), ldo, B, H, L, hd, code_of(Q)
-    if isinstance(O, Split):       # fp32 attention writing the next GEMM's split operand
+    if isinstance(Q, Split):       # split attention: Q, K, V and O are fp16 plane pairs
+        a.q_lo_off, a.kv_lo_off, a.o_lo_off = Q.lo_off, Kp.lo_off, O.lo_off
+    elif isinstance(O, Split):     # fp32 attention writing the next GEMM's split operand
         a.o_split, a.o_lo_off = O.code, O.lo_off
     a.scale, a.causal, a.slopes, a.period = scale, int(causal), _p(slopes), period
     check(lib().fdm_op_attention(C.byref(a), stream()))

@@ -29,9 +29,10 @@ extern "C" {
 /* Split operands (GEMM inputs only): x = hi + lo / S held as two planes of a 16-bit type, the lo plane `*_lo_off`
  * ELEMENTS after the hi plane, and the product evaluated as hi.hi + (hi.lo + lo.hi) / S in three passes of the 16-bit
  * MFMA with fp32 accumulation.  FDM_F16X3: fp16 planes, S = 2^11 (22 significant bits per operand: fp32-class results,
- * the mode that meets the 1e-4 contract on the 16-bit matrix cores; |x| is clamped to 65504).  FDM_BF16X3: bf16 planes,
- * S = 1 (16 bits per operand; ~5e-5 per denoiser call -- kept for comparison).  In these modes the QKV projection
- * writes fp32 Q / packed K / V (attention runs in fp32) and every producer of a GEMM input writes the plane pair. */
+ * the mode that meets the 1e-4 contract on the 16-bit matrix cores; |x| is clamped to 65504); its QKV projection writes Q and
+ * the packed K / V as plane pairs too and attention runs split (fdm_attn_args).  FDM_BF16X3: bf16 planes, S = 1 (16 bits per
+ * operand; ~5e-5 per denoiser call -- kept for comparison); its QKV projection writes fp32 Q / packed K / V and attention
+ * runs in fp32.  Every producer of a GEMM input writes the plane pair. */
 #define FDM_F16X3 2
 #define FDM_BF16X3 3
 
@@ -98,7 +99,8 @@ typedef struct fdm_gemm_args {
   const void* W; long long ldw; long long w_batch_stride;
   int M, N, K, batch;
   int dtype;                      /* FDM_F32 | FDM_BF16: type of A, W, out_t, out_kp, out_vp;
-                                     FDM_F16X3 | FDM_BF16X3: A, W, out_t are split plane pairs, out_kp / out_vp fp32 */
+                                     FDM_F16X3: A, W, out_t, out_kp, out_vp are fp16 plane pairs;
+                                     FDM_BF16X3: A, W, out_t are bf16 plane pairs, out_kp / out_vp fp32 */
   const float* bias; long long bias_batch_stride;
   int act;
   const float* resid; long long ldr; int resid_row_mod;
@@ -137,6 +139,7 @@ typedef struct fdm_gemm_args {
   fdm_sched_args sched;
   /* split operand kinds (dtype FDM_F16X3 / FDM_BF16X3): elements between the hi and lo planes of A, W and out_t */
   long long a_lo_off, w_lo_off, out_t_lo_off;
+  long long kv_lo_off;            /* FDM_F16X3 with out_kp / out_vp: elements between the hi and lo planes of the packed buffers */
 } fdm_gemm_args;
 #define FDM_TILE_AUTO 0
 #define FDM_TILE_64x64 1
@@ -185,6 +188,10 @@ typedef struct fdm_attn_args {
   /* o_split = FDM_F16X3 / FDM_BF16X3 (with dtype FDM_F32): O is written as a split plane pair (the next GEMM's input),
    * lo plane o_lo_off elements after the hi plane; 0 = O has the dtype of Q */
   int o_split; long long o_lo_off;
+  /* dtype FDM_F16X3: Q, Kp, Vp and O are fp16 plane pairs (the 16-bit packed layout, per plane); both products run as three
+   * 16-bit MFMA passes with the probabilities split in registers: fp32-class results.  q_lo_off / kv_lo_off / o_lo_off =
+   * elements between the hi and lo planes of Q / Kp and Vp / O. */
+  long long q_lo_off, kv_lo_off;
 } fdm_attn_args;
 int fdm_op_attention(const fdm_attn_args* a, void* stream);
 /* row-major K, V (row b*L + l, column h*hd + e, row strides ldk / ldv) -> the packed layouts above */

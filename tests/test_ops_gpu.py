@@ -215,6 +215,39 @@ def test_attention_via_qkv_gemm_layout(dtype, B, H, L, hd, causal, period):
     assert rel(o.float(), ref) < (3e-5 if dtype == F32 else 2e-2)
 
 
+@pytest.mark.parametrize("B,H,L,hd,causal,period", [(2, 8, 200, 128, True, 30), (1, 4, 37, 128, True, 25), (2, 3, 45, 64, False, 1),
+                                                    (1, 2, 600, 128, True, 30), (3, 2, 8, 128, True, 30)])
+def test_split_attention_via_qkv_gemm(B, H, L, hd, causal, period):
+    """FDM_F16X3: the QKV GEMM writes Q and the packed K / V as fp16 plane pairs, the split attention kernel runs both
+    products in three 16-bit MFMA passes (probabilities split in registers) and writes O as a plane pair.  Checked against an
+    fp64 evaluation of the same fp32 inputs at the fp32 kernel's own tolerance."""
+    g = torch.Generator().manual_seed(L + hd)
+    d = H * hd
+    x = torch.randn(B * L, d, generator=g)
+    Wqkv = torch.randn(3 * d, d, generator=g) / math.sqrt(d)
+    bqkv = 0.1 * torch.randn(3 * d, generator=g)
+    xs, ws = ops.to_operand(x.to(DEV), F16X3), ops.to_operand(Wqkv.to(DEV), F16X3)
+    Lpad = ops.kv_pad(L)
+    q = ops.Split.empty(B * L, d, F16X3, DEV)
+    kp = ops.Split(torch.zeros(2, B * H, Lpad * hd, device=DEV, dtype=torch.float16), F16X3)
+    vp = ops.Split(torch.zeros(2, B * H, Lpad * hd, device=DEV, dtype=torch.float16), F16X3)
+    ops.gemm(xs, ws, B * L, 3 * d, d, bias=bqkv.to(DEV), out_t=q, ldo_t=d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d,
+             kv_L=L, kv_Lpad=Lpad, kv_hd=hd)
+    slopes = torch.tensor([2.0 ** (-(i + 1)) for i in range(H)])
+    scale = 1.0 / math.sqrt(hd) if causal else 0.125
+    o = ops.Split.empty(B * L, d, F16X3, DEV)
+    ops.attention(q, kp, vp, o, B=B, H=H, L=L, hd=hd, ldq=d, ldo=d, Lpad=Lpad, scale=scale, causal=causal,
+                  slopes=slopes.to(DEV) if causal else None, period=period)
+    torch.cuda.synchronize()
+    qkv = x.double() @ Wqkv.double().t() + bqkv
+    qq, kk, vv = [t.view(B, L, H, hd).transpose(1, 2) for t in qkv.split(d, 1)]
+    kref, vref = pack_ref(kk.float(), vv.float(), Lpad, BF16)          # the 16-bit packed layout, per plane
+    assert rel(q.float(), qkv[:, :d]) < 2e-6
+    assert rel(kp.float(), kref) < 2e-6 and rel(vp.float(), vref) < 2e-6
+    ref = mha_ref(qq, kk, vv, scale, alibi(H, L, period, slopes).double() if causal else None).transpose(1, 2).reshape(B * L, d)
+    assert rel(o.float(), ref) < 3e-6
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("B,H,L,hd", [(2, 3, 45, 64), (1, 2, 100, 128), (1, 1, 33, 256)])
 def test_pack_kv_is_the_documented_permutation(dtype, B, H, L, hd):
