@@ -227,13 +227,25 @@ def main():
         fl = step_flops(p, B, L, cfg)
         step_ms = ev_ms / n_launch
         ach = fl / (step_ms * 1e-3) / 1e12
-        # HBM-side bytes per launch of the step graph: measured offline with rocprofv3 --pmc (bench.py cannot collect PMC
-        # counters on itself); taken from the committed summary when it was measured on this config, else null
-        traffic = None
+        # Counter-derived fields (HBM-side bytes per launch of the step graph, MFMA-busy share, the dominant kernel's own
+        # roofline entry) come from the committed rocprofv3 --pmc summary of THIS configuration and mode (bench.py cannot
+        # collect PMC counters on itself).  They are refused (null) when the summary was taken on another step program:
+        # its kernel-launch count per diffusion step must equal the running build's.
+        traffic = mfma_busy = dominant = prof_src = None
+        lps = plan.get("launches_per_step")
         try:
-            pm = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_summary.json")))
-            if pm.get("config") == a.config and pm.get("dtype") == a.dtype:
-                traffic = pm["traffic"]
+            prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r2_pmc_{a.config}_{a.dtype}")
+            pm = json.load(open(os.path.join(prof_dir, "summary.json")))
+            if int(round(pm["summary"]["launches_per_step"])) == int(lps) and not a.batch:
+                traffic = pm["summary"]["traffic_bytes_per_step"]
+                mfma_busy = pm["summary"]["mfma_busy_time_weighted"]
+                prof_src = f"profiles/r2_pmc_{a.config}_{a.dtype}/summary.json"
+                ks = [k for k in pm["kernels"] if "gemm" in k["kernel"]]
+                if ks:
+                    k = max(ks, key=lambda r: r["launches_per_step"] * r["avg_us"])
+                    dominant = {"name": k["kernel"], "launches_per_step": k["launches_per_step"], "avg_us_profiled": k["avg_us"],
+                                "mfma_busy": k.get("mfma_busy"), "wave_cycles_waiting": k.get("wait"), "l2_hit": k.get("l2_hit"),
+                                "fetch_mb": k.get("fetch_mb"), "write_mb": k.get("write_mb")}
         except (OSError, ValueError, KeyError):
             pass
         res = {
@@ -253,7 +265,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "denoiser step graph (one diffusion step, all kernels)",
                          "achieved": round(ach, 2), "peak": PEAK[a.dtype], "unit": "TFLOP/s",
                          "frac": round(ach / PEAK[a.dtype], 4), "traffic": traffic,
-                         "flops_per_launch": fl, "avg_launch_ms": round(step_ms, 5)},
+                         "flops_per_launch": fl, "avg_launch_ms": round(step_ms, 5),
+                         "mfma_busy": mfma_busy, "dominant_kernel": dominant, "counters_from": prof_src},
         }
         if not a.no_cpu_baseline and world == 1:
             # the bounded CPU sample is defined for the denoiser-only configs; cfg4/cfg5 reuse cfg2's shape class

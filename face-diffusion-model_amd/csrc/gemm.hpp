@@ -557,9 +557,7 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   const long long batch = a.batch > 0 ? a.batch : 1;
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
   if (a.sched_fuse) return gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true>(a, s);    // (validated: interior tiles only)
-  int tile = a.tile > 0 ? a.tile : gemm_tile_override();
-  if (tile >= FDM_TILE_64x64_K128_S3 && tile <= FDM_TILE_128x64_K128_S2 && a.K % (16 * (16 / (int)sizeof(T)))) tile = FDM_TILE_64x64;   // 128-deep k-tiles need K % 128 B
-  switch (tile) {
+  switch (a.tile > 0 ? a.tile : gemm_tile_override()) {
     case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);      // 8 waves, 32x16 per wave
     case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
     case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);  // 8 waves, 64x32 per wave
@@ -569,10 +567,6 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
     case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 32 KB -> 4 workgroups per CU
     case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);    // 4 waves, 16x32 per wave, 36 KB
-    case FDM_TILE_64x64_K128_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3, 16>(a, s);
-    case FDM_TILE_64x64_K128_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2, 16>(a, s);
-    case FDM_TILE_128x64_K128_S2: return gemm_glds_launch_t<T, 128, 64, 4, 2, 2, 16>(a, s);
-    case FDM_TILE_64x64_W4: return gemm_glds_launch_t<T, 64, 64, 2, 2, 4>(a, s);
     default: break;
   }
   // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;

@@ -151,11 +151,7 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_128x64_S3 7  /* 128x64 with a 3-stage ring (two workgroups per CU) */
 #define FDM_TILE_64x64_S2 8   /* 64x64 with a 2-stage ring (four workgroups per CU) */
 #define FDM_TILE_32x64_S3 9   /* 32x64 on 4 waves, 3-stage ring: twice the workgroups of 64x64 for few-hundred-row GEMMs */
-#define FDM_TILE_64x64_K128_S3 10   /* 64x64, 128-deep k-tiles (256-B LDS rows: half the barriers per K), 3-stage ring (96 KB) */
-#define FDM_TILE_64x64_K128_S2 11   /* the same with a 2-stage ring (64 KB: two workgroups per CU) */
-#define FDM_TILE_128x64_K128_S2 12  /* 128x64, 128-deep k-tiles, 2-stage ring (96 KB) */
-#define FDM_TILE_64x64_W4 13        /* 64x64 on 4 waves (32x32 per wave), 4-stage ring (64 KB: two workgroups per CU) */
-#define FDM_TILE_MAX 13
+#define FDM_TILE_MAX 9
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -10,7 +10,7 @@ from fdm_amd._lib import DTYPE_NAMES, F32, ACT_RELU, ACT_NONE
 DEV = 'cuda:0'
 dt = DTYPE_NAMES[sys.argv[1]] if len(sys.argv) > 1 else 1
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 800
-tiles = [int(t) for t in sys.argv[3:]] or list(range(0, 14))
+tiles = [int(t) for t in sys.argv[3:]] or list(range(0, 10))
 shapes = {"out N1024 K1024": (1024, 1024, ACT_NONE), "qkv N3072 K1024": (3072, 1024, ACT_NONE), "ffn1 N2048 K1024": (2048, 1024, ACT_RELU),
           "ffn2 N1024 K2048": (1024, 2048, ACT_NONE)}
 g = torch.Generator().manual_seed(0)
