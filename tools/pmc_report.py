@@ -21,9 +21,9 @@ def short(name):
         if name not in _DEMANGLED:
             import shutil
             import subprocess
-            tool = shutil.which("c++filt") or shutil.which("llvm-cxxfilt") or "/opt/rocm/lib/llvm/bin/llvm-cxxfilt"
-            try:
-                _DEMANGLED[name] = subprocess.run([tool, name], capture_output=True, text=True, timeout=10).stdout.strip() or name
+            tool = shutil.which("llvm-cxxfilt") or shutil.which("c++filt") or "c++filt"
+            try:      # (GNU c++filt does not know DF16b = __bf16: spell it as a vendor type)
+                _DEMANGLED[name] = subprocess.run([tool, name.replace("DF16b", "u6__bf16")], capture_output=True, text=True, timeout=10).stdout.strip() or name
             except Exception:
                 _DEMANGLED[name] = name
         name = _DEMANGLED[name]
