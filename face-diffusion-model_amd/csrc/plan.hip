@@ -504,14 +504,17 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
   int* step = P->step; int* tcur = P->step + 1;
   const float* none = nullptr; (void)none;
   const float *b = nullptr;
-  for (int r = 0; r < P->rep; ++r) {
-    const size_t o = (size_t)r * M;
+  {
+    // latent encoder: h = act(x W^T + b) + E0.  A CFG plan's cond and uncond rows read the same x rows and differ only in
+    // the addend, so both halves are one batched launch (batch index = half: A / W / bias strides 0, outputs and the
+    // addend advance by M rows).  First kernel of the step: the step counter += 1 and tcur = tseq[counter].
     FCK(need(P, "latent_encoder.0.bias", d, &b));
     fdm_gemm_args g = gemm_op(P, P->xt, P->wt["latent_encoder.0.weight"], M, d, d);
     g.bias = b; g.act = m.latent_mish ? FDM_ACT_MISH : FDM_ACT_NONE;
-    g.resid = P->E0 + o * d; g.out_f32 = P->h + o * d;
-    if (both) set_out_t(g, mat_rows(P, P->ht, o, d));
-    if (r == 0) { g.incr_counter = step; g.incr_table = P->tseq; }      // first kernel of the step: counter += 1, tcur = tseq[counter]
+    g.resid = P->E0; g.out_f32 = P->h;
+    if (both) set_out_t(g, P->ht);
+    g.batch = P->rep; g.out_batch_stride = (long long)M * d;
+    g.incr_counter = step; g.incr_table = P->tseq;
     FCK(plan_gemm(P, "enc", g, stream));
   }
   const int BB = P->B * P->rep;
