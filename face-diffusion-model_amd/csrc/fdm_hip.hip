@@ -102,7 +102,6 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (split && (a->a_lo_off <= 0 || a->w_lo_off <= 0 || a->a_lo_off % epc || a->w_lo_off % epc))
     return fail(FDM_ERR_ARG, "gemm: split operands need positive a_lo_off / w_lo_off (multiples of 8 elements)");
   if (split && a->out_t && a->out_t_lo_off <= 0) return fail(FDM_ERR_ARG, "gemm: split out_t needs out_t_lo_off");
-  if (split && (a->stat_out || a->ln_stat_in)) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding is a bf16-mode feature");
   if (a->K % bk) return fail(FDM_ERR_SHAPE, "gemm: K=%d not a multiple of %d", a->K, bk);
   if (a->lda % epc || a->ldw % epc || !aligned16(a->A) || !aligned16(a->W)) return fail(FDM_ERR_ARG, "gemm: operands need 16-byte aligned rows");
   if (a->a_batch_stride % epc || a->w_batch_stride % epc) return fail(FDM_ERR_ARG, "gemm: batch strides need 16-byte alignment");

@@ -51,6 +51,16 @@ __global__ __launch_bounds__(256) void rowsum_bf16_kernel(const fdm::bf16* W, fl
   s = fdm::wave_sum(s);
   if (lane == 0) out[row] = s;
 }
+// the same for a split operand: the value a GEMM sees is hi + lo / scale
+template <typename E>
+__global__ __launch_bounds__(256) void rowsum_split_kernel(const E* W, long long lo_off, float inv_scale, float* out, int N, int K) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += (float)W[(size_t)row * K + k] + (float)W[lo_off + (size_t)row * K + k] * inv_scale;
+  s = fdm::wave_sum(s);
+  if (lane == 0) out[row] = s;
+}
 int grid_for(long long n) { long long b = (n + 255) / 256; return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b)); }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -382,7 +392,8 @@ int commit(fdm_plan* P, void* stream) {
   // bf16 step program: norm3 of layer l-1 folded into the QKV / out-proj GEMMs of layer l and into the latent decoder
   //   LN(x) W^T + b = rstd (x W'^T - mu colsum(W')) + (W beta + b),  W' = W o gamma
   const char* env = getenv("FDM_FUSE_LN3");
-  P->fuse_ln3 = P->dtype == FDM_BF16 && !(env && !strcmp(env, "0"));
+  // (default on in bf16; f16x3: opt-in with FDM_FUSE_LN3=1 -- same algebra on the plane pairs)
+  P->fuse_ln3 = (P->dtype == FDM_BF16 && !(env && !strcmp(env, "0"))) || (P->dtype == FDM_F16X3 && env && !strcmp(env, "1"));
   if (P->fuse_ln3) {
     auto make_fold = [&](const std::string& wname, const std::string& bname, int N, int l_prev, Fold* f) -> int {
       const float *W = nullptr, *b = nullptr, *gam = nullptr, *bet = nullptr;
@@ -395,7 +406,10 @@ int commit(fdm_plan* P, void* stream) {
       hipLaunchKernelGGL(scale_cols_kernel, dim3(grid_for((long long)N * d)), dim3(256), 0, s, W, gam, wg, (long long)N * d, d);
       FCK(to_operand(P, wg, (long long)N * d, &f->w, stream));
       FCK(dalloc_t(P, &f->colsum, (size_t)N, false));
-      hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, s, (const fdm::bf16*)f->w.p, f->colsum, N, d);
+      if (P->dtype == FDM_BF16)
+        hipLaunchKernelGGL(rowsum_bf16_kernel, dim3((N + 3) / 4), dim3(256), 0, s, (const fdm::bf16*)f->w.p, f->colsum, N, d);
+      else
+        hipLaunchKernelGGL(rowsum_split_kernel<fdm::f16>, dim3((N + 3) / 4), dim3(256), 0, s, (const fdm::f16*)f->w.p, f->w.lo, 1.f / 2048.f, f->colsum, N, d);
       FCK(dalloc_t(P, &f->bias, (size_t)N, false));
       FCK(fdm_op_small_linear(bet, W, b, f->bias, 1, d, N, FDM_ACT_NONE, stream));      // W beta + b
       f->gamma = gam; f->beta = bet;
@@ -466,7 +480,7 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   } else {        // fp32 operands alias the fp32 residual-stream buffers
     P->xt = Mat{P->x, 0}; P->ht = Mat{P->h, 0}; P->h2t = Mat{P->h2, 0};
   }
-  if (P->dtype == FDM_BF16) {
+  if (P->dtype == FDM_BF16 || P->dtype == FDM_F16X3) {     // folded-norm3 buffers (raw rows, their operand copy, per-row partial sums)
     FCK(dalloc_t(P, &P->x2, R * d, true)); FCK(dalloc_mat(P, &P->x2t, R, d, true)); FCK(dalloc_t(P, &P->stats, (d / 64) * R * 2, true));
   }
   // q: row-major queries; kp / vp: fragment-packed keys / values written by the QKV GEMM's epilogue (zeroed: pad keys must be

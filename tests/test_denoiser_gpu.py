@@ -221,6 +221,25 @@ def test_bf16_folded_norm3_matches_unfolded(monkeypatch):
     assert mad(outs["1"], outs["0"]) < TOLBF
 
 
+def test_f16x3_folded_norm3_is_opt_in_and_stays_in_contract(monkeypatch):
+    """FDM_FUSE_LN3=1 folds norm3 into the surrounding GEMMs in the split-fp16 program too (the same algebra on plane pairs:
+    8 launches fewer, ~1 % faster -- off by default): still inside the 1e-4 contract of the reference goldens."""
+    L, t = 50, 777
+    inp = W.synth_inputs("vocaset", 2, L, seed=31)
+    w = W.make_fdm_weights("vocaset")
+    ref = FO.fdm_forward(w, "vocaset", inp["hub"], t, inp["x"], inp["style"], None, folded=True)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FDM_FUSE_LN3", flag)
+        plan = DenoiserPlan("vocaset", w, F16X3, DEV)
+        assert plan.fuse_ln3 == (flag == "1")
+        plan.prepare(inp["hub"], inp["style"], L=L)
+        outs[flag] = plan.denoise(inp["x"].to(DEV), t).cpu()
+        assert mad(outs[flag], ref) < TOL32
+    monkeypatch.delenv("FDM_FUSE_LN3")
+    assert DenoiserPlan("vocaset", w, F16X3, DEV).fuse_ln3 is False
+
+
 def test_full_size_cfg2_chain_properties():
     """BASELINE.json configs[1] at full size (4 clips x 200 frames, 1000 DDPM steps): the oracle cannot finish this in
     seconds, so the chain is checked through size-independent properties: run-to-run determinism, clip
