@@ -809,6 +809,35 @@ int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
                             FDM_TILE_128x128, FDM_TILE_96x128};
   if (is_split(P->dtype)) cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64_S3, FDM_TILE_128x128};
   else if (P->R >= 1024) cands.push_back(FDM_TILE_256x128);
+  // Which of them are worth a stopwatch is decided by a wave-quantisation model first.  What bounds these GEMMs is the
+  // bytes a CU pulls from L2 into LDS: a BM x BN tile costs (BM + BN) * K * bytes-per-element (x planes)
+  // and the busiest CU runs ceil(tiles / 256) of them (the whole grid is resident, or queued behind, at <= 160 KB / ring per CU),
+  // on top of a fixed cost per kernel (~5 us: boundary, ring fill, epilogue; in-situ timings of profiles/README.md fit
+  // 5 us + bytes / 70 GB/s within ~15 % for tiles up to 128x64; larger tiles run above the model).  Candidates modelled
+  // more than 35 % above the best one are not timed.
+  struct Geo { int bm, bn, nst; };
+  auto geo = [&](int tile) -> Geo {
+    const bool sp = is_split(P->dtype);
+    switch (tile) {
+      case FDM_TILE_64x64_S3: return {64, 64, 3};
+      case FDM_TILE_64x64_S2: return {64, 64, 2};
+      case FDM_TILE_32x64_S3: return {32, 64, 3};
+      case FDM_TILE_128x64: return {128, 64, sp ? 3 : 4};
+      case FDM_TILE_128x64_S3: return {128, 64, 3};
+      case FDM_TILE_128x128: return {128, 128, sp ? 2 : 3};
+      case FDM_TILE_96x128: return {96, 128, 4};
+      case FDM_TILE_256x128: return {256, 128, 3};
+      default: return {64, 64, 4};
+    }
+  };
+  auto modelled_us = [&](const fdm_gemm_args& a, int tile) {
+    const Geo g = geo(tile);
+    const double planes = is_split(P->dtype) ? 2.0 : 1.0, eb = P->dtype == FDM_F32 ? 4.0 : 2.0;
+    const long long tiles = (long long)((a.M + g.bm - 1) / g.bm) * ((a.N + g.bn - 1) / g.bn) * (a.batch > 0 ? a.batch : 1);
+    const long long rounds = (tiles + 255) / 256;                                   // tiles on the busiest CU
+    const double bytes = (double)rounds * (g.bm + g.bn) * a.K * eb * planes;
+    return 5.0 + bytes / 70e3;          // us
+  };
   std::map<std::string, int> tuned, runner_up;
   for (auto& kv : calls) {
     std::vector<fdm_gemm_args> inst = kv.second;
@@ -816,7 +845,14 @@ int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
     float base = 0.f;
     FCK(timed(inst, 0, &base));
     std::vector<std::pair<float, int>> cand = {{base * 0.97f, 0}};          // switch only for a > 3 % gain over the heuristic
-    for (int tile : cands) { float t = 0.f; FCK(timed(inst, tile, &t)); cand.push_back({t, tile}); }
+    double best_model = 1e30;
+    for (int tile : cands) best_model = std::min(best_model, modelled_us(kv.second[0], tile));
+    for (int tile : cands) {
+      if (modelled_us(kv.second[0], tile) > 1.35 * best_model) continue;
+      float t = 0.f;
+      FCK(timed(inst, tile, &t));
+      cand.push_back({t, tile});
+    }
     std::sort(cand.begin(), cand.end());
     tuned[kv.first] = cand[0].second;
     if (cand.size() > 1 && cand[1].first < cand[0].first * 1.05f) runner_up[kv.first] = cand[1].second;   // settled inside the chain below
