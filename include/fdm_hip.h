@@ -293,9 +293,11 @@ int fdm_prog_run_lanes(fdm_prog* p, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Plan layer.  A plan owns device copies of the model's weights, the tables derived from them,
- * its workspaces and the recorded step program; the caller owns every tensor it passes in.  The only functions that
- * allocate or synchronise are fdm_plan_create / _reserve / _commit / _tune / _destroy and the first fdm_sample_graph /
- * fdm_denoise_step call of a program shape (graph instantiation).  A plan is not thread-safe; one plan per device/stream.
+ * its workspaces and the recorded step program; the caller owns every tensor it passes in.  Device memory is allocated only
+ * by fdm_plan_create / _reserve / _commit (and by fdm_audio_prepare when it has to grow the workspaces or commit first);
+ * fdm_sample_graph / fdm_denoise_step drain the stream once per call while uploading the timestep list (host memory of the
+ * caller) and instantiate a graph the first time a program shape is used; nothing synchronises inside the T-step loop.
+ * A plan is not thread-safe; one plan per device/stream.
  *
  * Model geometry = the reference constructors' numbers (models/fdm_vocaset.py:9-51, models/fdm_vqvae_mead.py:9-53,
  * models/fdm.py:10-48, models/utils/config.py): fdm_model_preset fills it for "vocaset", "mead", "biwi" (+ "_tiny" test twins). */

@@ -118,3 +118,36 @@ def test_program_recording_and_split_validation_without_device():
     assert l.fdm_prog_replay(h, 1, None) == -4             # not instantiated
     assert l.fdm_prog_destroy(h) == 0
     assert l.fdm_plan_get(None, b"rows", C.byref(C.c_longlong())) == -1
+
+
+def test_plan_layer_argument_validation_without_device():
+    """The plan layer reports bad arguments before touching a device (null handles, bad geometry / kinds / dtypes)."""
+    from fdm_amd import _lib
+    l = _lib.lib()
+    assert l.fdm_plan_reserve(None, 1, 10, 0) == -1
+    assert l.fdm_plan_commit(None, None) == -1
+    assert l.fdm_plan_set_weights(None, b"x", 16, 4, None) == -1
+    assert l.fdm_audio_prepare(None, 16, 1, 10, 1024, 16, None, 10, 0, None) == -1
+    assert l.fdm_denoise_step(None, 16, 0, 0.0, 16, None, None) == -1
+    assert l.fdm_sample_graph(None, C.byref(_lib.SampleArgs()), None) == -1
+    assert l.fdm_plan_tune(None, None) == -1
+    assert l.fdm_plan_destroy(None) == 0
+    h = C.c_void_p()
+    assert l.fdm_hubert_create(2, 0, 0, C.byref(h)) == -1 and b"kind" in l.fdm_last_error()
+    assert l.fdm_hubert_create(0, 0, _lib.F16X3, C.byref(h)) == -1                       # the once-per-clip stages: fp32 / bf16
+    assert l.fdm_hubert_create(1, 0, 0, C.byref(h)) == 0                                 # creation itself needs no device
+    assert l.fdm_hubert_set_weights(h, b"encoder.layer_norm.weight", None, 768, None) == -1
+    assert l.fdm_hubert_destroy(h) == 0
+    assert l.fdm_hubert_frames(32000) == 98 and l.fdm_hubert_frames(32080) == 100 and l.fdm_hubert_frames(160000) == 498
+    assert l.fdm_hubert_frames(100) == 0
+    d = _lib.VqDesc(16, 64, 256, 1, 15069, 0)
+    v = C.c_void_p()
+    assert l.fdm_vq_create(C.byref(d), 0, C.byref(v)) == 0 and l.fdm_vq_destroy(v) == 0
+    d.c = 200
+    assert l.fdm_vq_create(C.byref(d), 0, C.byref(v)) == -2
+    d = _lib.VqDesc(8, 64, 256, 7, 15069, 0)                                             # G * c != 1024 without a pre-embedding
+    assert l.fdm_vq_create(C.byref(d), 0, C.byref(v)) == -2
+    pd = _lib.ModelDesc()
+    assert l.fdm_model_preset(b"biwi", C.byref(pd)) == 0 and pd.d // pd.n_head == 256
+    p = C.c_void_p()
+    assert l.fdm_plan_create(C.byref(pd), 1, 10, 0, _lib.F16X3, C.byref(p)) == -2 and b"head_dim" in l.fdm_last_error()
