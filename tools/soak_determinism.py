@@ -3,12 +3,13 @@ the recorded-program replay and the tuner's tile switches)."""
 import sys, torch
 sys.path.insert(0, 'face-diffusion-model_amd'); sys.path.insert(0, '.')
 from fdm_amd.denoiser import DenoiserPlan
-from fdm_amd._lib import BF16, F32
+from fdm_amd._lib import BF16, F16X3, F32
 from fdm_amd import synth as W
 DEV = 'cuda:0'
 for preset, B, L, T, cfg, dt, reps in (("vocaset", 4, 200, 1000, False, BF16, 6), ("vocaset", 4, 498, 400, False, BF16, 4),
                                        ("mead", 4, 300, 400, True, BF16, 4), ("vocaset", 4, 200, 300, False, F32, 3),
-                                       ("biwi", 4, 200, 250, False, BF16, 4)):
+                                       ("biwi", 4, 200, 250, False, BF16, 4), ("vocaset", 4, 200, 1000, False, F16X3, 4),
+                                       ("mead", 4, 300, 400, True, F16X3, 3), ("vocaset", 4, 498, 300, False, F16X3, 3)):
     inp = W.synth_inputs(preset, B, L, seed=2)
     plan = DenoiserPlan(preset, W.make_fdm_weights(preset), dt, DEV)
     hub = inp["hub"][:, :, :768].contiguous() if preset == "biwi" else inp["hub"]
@@ -22,4 +23,4 @@ for preset, B, L, T, cfg, dt, reps in (("vocaset", 4, 200, 1000, False, BF16, 6)
         assert torch.isfinite(out).all()
         if ref is None: ref = out.clone()
         assert torch.equal(out, ref), f"{preset} L={L} run {r} differs: max {float((out - ref).abs().max())}"
-    print(f"{preset} B={B} L={L} T={T} cfg={cfg} {'bf16' if dt == BF16 else 'fp32'}: {reps} runs bit-identical, tiles {plan.tiles}")
+    print(f"{preset} B={B} L={L} T={T} cfg={cfg} { {BF16: 'bf16', F32: 'fp32', F16X3: 'f16x3'}[dt] }: {reps} runs bit-identical, tiles {plan.tiles}")
