@@ -91,7 +91,6 @@ int fdm_device_ok(void) {
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
-static bool device_ok() { static const int ok = fdm_device_ok(); return ok != 0; }
 static bool gemm_act_heavy_host(int act) { return act == FDM_ACT_MISH || act == FDM_ACT_GELU_ERF || act == FDM_ACT_GELU_TANH; }
 
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
@@ -134,39 +133,8 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
     if (sc.mode == 1 && (!sc.sra || !sc.srm1 || !sc.sqrt_an || !sc.c_n)) return fail(FDM_ERR_ARG, "gemm: fused DDIM needs sra, srm1, sqrt_an, c_n");
     if (sc.mode == 0 && !sc.noise && sc.n_per_clip <= 0) return fail(FDM_ERR_ARG, "gemm: fused DDPM with Philox noise needs n_per_clip");
   }
-  if (a->lnx_gamma) {
-    if (!a->lnx_beta || !a->lnx_slots || !a->lnx_epoch || !a->lnx_err) return fail(FDM_ERR_ARG, "gemm: lnx needs lnx_beta, lnx_slots, lnx_epoch and lnx_err");
-    if ((a->lnx_gamma2 != nullptr) != (a->lnx_beta2 != nullptr)) return fail(FDM_ERR_ARG, "gemm: lnx_gamma2 and lnx_beta2 go together");
-    if ((a->lnx_add_mat || a->lnx_add_tab) && !a->lnx_gamma2) return fail(FDM_ERR_ARG, "gemm: lnx addends belong to the second LayerNorm (lnx_gamma2)");
-    if (a->lnx_site < 0 || (a->lnx_site & 31) != (a->lnx_site & ~(256 | 512 | 1024))) return fail(FDM_ERR_ARG, "gemm: lnx_site must be in [0, 32)");
-    if (a->N % 64 || a->N > 1024 || a->batch > 1 || a->out_batch_stride || a->resid_row_mod)
-      return fail(FDM_ERR_SHAPE, "gemm: lnx needs N %% 64 == 0, N <= 1024 and an unbatched call");
-    if (a->lnx_slot_rows < (a->M + 255) / 256 * 256) return fail(FDM_ERR_ARG, "gemm: lnx_slot_rows must cover M rounded up to 256");
-    if (a->act != FDM_ACT_NONE || a->stat_out || a->ln_stat_in || a->out_kp || a->out_vp || a->sched_fuse)
-      return fail(FDM_ERR_ARG, "gemm: lnx cannot be combined with an activation, LayerNorm folding, packed K/V or the fused scheduler");
-    if ((a->out_f32 && (a->ldo_f32 % 4 || !aligned16(a->out_f32))) || (a->out_t && (a->ldo_t % 4 || !aligned16(a->out_t) || a->out_t_lo_off % 4)) ||
-        (a->resid && (a->ldr % 4 || !aligned16(a->resid))) || !aligned16(a->lnx_gamma) || !aligned16(a->lnx_beta) || !aligned16(a->lnx_gamma2) ||
-        !aligned16(a->lnx_beta2) || !aligned16(a->lnx_add_mat) || !aligned16(a->lnx_add_tab) || ((uintptr_t)a->lnx_slots & 7))
-      return fail(FDM_ERR_ARG, "gemm: lnx needs 16-byte aligned outputs, residual and vectors (leading dimensions multiples of 4)");
-    if (!device_ok()) return fail(FDM_ERR_STATE, "gemm: no gfx950 device");
-    // residency of the whole launch (the exchange waits on peers): explicit tile, else the first default tile that fits
-    bool fits = false;
-    const int cand[4] = {FDM_TILE_64x64, FDM_TILE_64x64_S2, FDM_TILE_128x64, FDM_TILE_128x128};
-    for (int i = 0; i < (a->tile > 0 ? 1 : 4) && !fits; ++i) {
-      int bm = 0, bn = 0;
-      const int cap = fdm::gemm_lnx_capacity(a->dtype, a->tile > 0 ? a->tile : cand[i], &bm, &bn);
-      fits = a->N % bn == 0 && (long long)((a->M + bm - 1) / bm) * (a->N / bn) <= cap;
-    }
-    if (!fits) return fail(FDM_ERR_SHAPE, "gemm: lnx launch of %d x %d rows x columns does not fit the device's resident workgroups (tile %d)", a->M, a->N, a->tile);
-  }
   fdm_gemm_args c = *a;
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
-}
-
-int fdm_op_gemm_lnx_capacity(int dtype, int tile, int* bm, int* bn) {
-  if (dtype < FDM_F32 || dtype > FDM_BF16X3 || tile < 0 || tile > FDM_TILE_MAX) return fail(FDM_ERR_ARG, "gemm_lnx_capacity: bad dtype / tile");
-  if (!device_ok()) return fail(FDM_ERR_STATE, "gemm_lnx_capacity: no gfx950 device");
-  return fdm::gemm_lnx_capacity(dtype, tile, bm, bn);
 }
 
 int fdm_op_attention(const fdm_attn_args* a, void* stream) {

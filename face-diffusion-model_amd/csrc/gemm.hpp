@@ -356,199 +356,6 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Row-group LayerNorm epilogue (fdm_gemm_args.lnx_*): y = LN(x) or LN2(LN1(x) + addends) with x = acc + bias + resid, for the
-// GEMMs whose output feeds a LayerNorm (out-proj -> norm1 + norm2, FFN2 -> norm3).  The N / BN workgroups of a row block
-// each hold BN columns of its rows, so per LayerNorm they exchange per-64-column partials once, inside the launch:
-//   fragment sums (16 columns: 4 per lane, rows_sum over the 4 lane groups) -> LDS -> 64-column (sum S, M2 about S / 64)
-//   -> published as two 8-byte {tag, value} words (relaxed agent-scope atomic stores: the data is the flag, no fence,
-//      cdna_hip_programming.md Guideline 16 R2) -> every workgroup collects the N / 64 partials of its BM rows with relaxed
-//      agent-scope atomic loads until all tags match (bounded) -> Chan's combination in column order -> mu, rstd per row.
-// Every order above is fixed by the column index alone, so the statistics do not depend on the tile.  Measured in
-// isolation (tools/row_exchange_probe.cpp) a round costs ~2.0-2.2 us against 5.4 + 1.7 us for a LayerNorm launch and its
-// boundary.  The 1-D grid is decoded so that the column tiles of a row block have equal blockIdx % 8 (one XCD under the
-// observed round-robin placement: speed only, the protocol is placement-independent).
-// ---------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(1))) unsigned long long lnx_gu64;
-constexpr unsigned LNX_SPIN_LIMIT = 1u << 15;
-
-template <typename T, int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void gemm_epilogue_lnx(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
-                                                  const EpiPre<BM / WM / 16, BN / WN / 16>& e, int m0, int n0, int wm, int wn,
-                                                  int g, int r16, float* rowstat, char* ring) {
-  constexpr int MI = BM / WM / 16, NI = BN / WN / 16, NTH = 64 * WM * WN;
-  constexpr int NF = BN / 16, NGT = BN / 64;        // 16-column fragments / 64-column groups per tile row
-  using E = typename Opnd<T>::E;
-  const int M = p.M, N = p.N, NG = N / 64;
-  float* comb = (float*)ring;                       // [NF][BM] fragment sums
-  float* comb2 = comb + NF * BM;                    // [NF][BM] fragment M2 about the group mean
-  const int tid = threadIdx.x;
-  const unsigned tag = p.lnx_epoch[0] * 32u + (unsigned)(p.lnx_site & 31);
-  const bool nowait = (p.lnx_site & 256) != 0;       // EXPERIMENT: accept whatever the slots hold
-  const bool two = p.lnx_gamma2 != nullptr;
-  const int ncol = n0 + wn * (BN / WN) + 4 * g;     // this lane's first column in fragment ni = 0
-  f32x4 v[MI][NI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      v[mi][ni] = acc[mi][ni];
-      if (p.bias) v[mi][ni] += e.bv[ni];
-      if (p.resid) v[mi][ni] += e.rv[mi][ni];
-    }
-  // vectors of the affine maps and the second stage's addends: requested now, first used after the first exchange
-  f32x4 g1[NI], b1[NI], g2[NI], b2[NI], ad[MI][NI];
-  const int tabrow = p.lnx_add_tab ? (p.lnx_tab_step ? *p.lnx_tab_step : 0) : 0;
-#pragma unroll
-  for (int ni = 0; ni < NI; ++ni) {
-    const int n = ncol + ni * 16;
-    g1[ni] = *(const f32x4*)(p.lnx_gamma + n); b1[ni] = *(const f32x4*)(p.lnx_beta + n);
-    if (two) { g2[ni] = *(const f32x4*)(p.lnx_gamma2 + n); b2[ni] = *(const f32x4*)(p.lnx_beta2 + n); }
-    f32x4 tr = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (two && p.lnx_add_tab) tr = *(const f32x4*)(p.lnx_add_tab + (size_t)tabrow * N + n);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int m = min(m0 + wm * (BM / WM) + mi * 16 + r16, M - 1);
-      ad[mi][ni] = tr;
-      if (two && p.lnx_add_mat) ad[mi][ni] += *(const f32x4*)(p.lnx_add_mat + (size_t)m * N + n);
-    }
-  }
-  bool poisoned = false;
-  __syncthreads();                                  // every wave is done reading the last ring stage
-  auto exchange = [&](int round, float (&mu)[MI], float (&rs)[MI]) {
-    if (p.lnx_site & 512) {                        // EXPERIMENT: no exchange at all
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) { mu[mi] = 0.f; rs[mi] = 0.05f; }
-      return;
-    }
-    // 1. fragment sums
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int lrow = wm * (BM / WM) + mi * 16 + r16;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const f32x4& x = v[mi][ni];
-        const float fs = rows_sum((x[0] + x[1]) + (x[2] + x[3]));
-        if (g == 0) comb[(wn * NI + ni) * BM + lrow] = fs;
-      }
-    }
-    __syncthreads();
-    // 2. M2 of each fragment about its 64-column group's mean
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int lrow = wm * (BM / WM) + mi * 16 + r16;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-        const int f = wn * NI + ni;
-        const float* c = comb + (f & ~3) * BM + lrow;
-        const float gm = ((c[0] + c[BM]) + (c[2 * BM] + c[3 * BM])) * (1.f / 64.f);
-        const f32x4 dx = v[mi][ni] - gm;
-        const float fq = rows_sum((dx[0] * dx[0] + dx[1] * dx[1]) + (dx[2] * dx[2] + dx[3] * dx[3]));
-        if (g == 0) comb2[f * BM + lrow] = fq;
-      }
-    }
-    __syncthreads();
-    // 3. publish this tile's 64-column partials: two granules per (group, row)
-    lnx_gu64* slots = (lnx_gu64*)p.lnx_slots + (size_t)round * p.lnx_slot_rows * NG * 2;
-    for (int i = tid; i < BM * NGT; i += NTH) {
-      const int row = i % BM, gq = i / BM;
-      const float* c = comb + gq * 4 * BM + row;
-      const float* q = comb2 + gq * 4 * BM + row;
-      const float S = (c[0] + c[BM]) + (c[2 * BM] + c[3 * BM]);
-      const float Q = (q[0] + q[BM]) + (q[2 * BM] + q[3 * BM]);
-      lnx_gu64* sp = slots + ((size_t)(n0 / 64 + gq) * p.lnx_slot_rows + m0 + row) * 2;
-      __hip_atomic_store(sp, ((unsigned long long)tag << 32) | __float_as_uint(S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(sp + 1, ((unsigned long long)tag << 32) | __float_as_uint(Q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // 4. thread (row, which) collects its row's NG granules: all loads in flight at once, only the granules whose tag has
-    //    not matched yet are requested again (the polling traffic shrinks to the late peers' words)
-    if (tid < 2 * BM) {
-      const int row = tid >> 1, which = tid & 1;
-      const lnx_gu64* rp = slots + ((size_t)m0 + row) * 2 + which;
-      float val[16];
-      unsigned pending = NG >= 16 ? 0xffffu : ((1u << NG) - 1u);
-      if (p.lnx_site & 1024) {      // EXPERIMENT (1024): LDS phases and publish only
-        pending = 0;
-#pragma unroll
-        for (int gq = 0; gq < 16; ++gq) val[gq] = which ? 400.f * N / NG : 0.f;
-      }
-      for (unsigned spins = 0;; ++spins) {
-        unsigned long long x[16];
-#pragma unroll
-        for (int gq = 0; gq < 16; ++gq)
-          if (pending >> gq & 1u) x[gq] = __hip_atomic_load(rp + (size_t)gq * p.lnx_slot_rows * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int gq = 0; gq < 16; ++gq)
-          if ((pending >> gq & 1u) && ((unsigned)(x[gq] >> 32) == tag || nowait)) { val[gq] = __uint_as_float((unsigned)x[gq]); pending &= ~(1u << gq); }
-        if (!pending) break;
-        if (spins >= LNX_SPIN_LIMIT || __hip_atomic_load(p.lnx_err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          atomicAdd(p.lnx_err, 1u);                 // a peer never published: not resident (refused at launch) or a fault
-          poisoned = true;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      // 5. the lane pair swaps S and M2; both combine the NG equal-sized partials in column order (Chan's formula)
-      float sum = 0.f, S[16], Q[16];
-#pragma unroll
-      for (int gq = 0; gq < 16; ++gq) {
-        const float mine = gq < NG ? val[gq] : 0.f;
-        const float other = __shfl_xor(mine, 1, 64);
-        S[gq] = which ? other : mine; Q[gq] = which ? mine : other;
-        if (gq < NG) sum += S[gq];
-      }
-      const float mean = sum / (float)N;
-      float m2 = 0.f;
-#pragma unroll
-      for (int gq = 0; gq < 16; ++gq) {
-        const float dm = S[gq] * (1.f / 64.f) - mean;
-        if (gq < NG) m2 += Q[gq] + 64.f * dm * dm;
-      }
-      if (which == 0) { rowstat[2 * row] = mean; rowstat[2 * row + 1] = 1.f / sqrtf(m2 / (float)N + p.ln_eps); }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      const int lrow = wm * (BM / WM) + mi * 16 + r16;
-      mu[mi] = rowstat[2 * lrow]; rs[mi] = rowstat[2 * lrow + 1];
-    }
-  };
-  float mu[MI], rs[MI];
-  exchange(0, mu, rs);
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) v[mi][ni] = (v[mi][ni] - mu[mi]) * rs[mi] * g1[ni] + b1[ni];
-  if (two) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) v[mi][ni] += ad[mi][ni];
-    exchange(1, mu, rs);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) v[mi][ni] = (v[mi][ni] - mu[mi]) * rs[mi] * g2[ni] + b2[ni];
-  }
-  if (__syncthreads_or(poisoned)) {
-    const float nan = __uint_as_float(0x7fc00000u);
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) v[mi][ni] = f32x4{nan, nan, nan, nan};
-  }
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int m = m0 + wm * (BM / WM) + mi * 16 + r16;
-    if (m >= M) continue;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-      if (p.out_f32) *(f32x4*)(p.out_f32 + (size_t)m * p.ldo_f32 + ncol + ni * 16) = v[mi][ni];
-      if (p.out_t) store_opnd4<T>((E*)p.out_t + (size_t)m * p.ldo_t + ncol + ni * 16, p.out_t_lo_off, v[mi][ni]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
 // Main loop: HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging) into an NST-stage
 // ring, tiles prefetched NST-1 deep, counted s_waitcnt vmcnt (never 0 in steady state), one raw
 // s_barrier per k-tile.  The LDS image of a stage is lane-linear (a wave instruction writes 1 KiB =
@@ -562,7 +369,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, bool LNX = false>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
   using E = typename Opnd<T>::E;
@@ -576,8 +383,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   constexpr int P = NP * (A_IPW + W_IPW);
   constexpr int STAGE = NP * (BM + BN) * ROWB;   // [A planes][W planes]
   static_assert(NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>(), "epilogue staging does not fit in the ring");
-  static_assert(!LNX || NST * STAGE >= 2 * (BN / 16) * BM * 4, "row-group LayerNorm scratch does not fit in the ring");
-  static_assert(!LNX || 2 * BM <= 64 * WM * WN, "row-group LayerNorm: two threads per tile row");
   constexpr bool EARLY_READS = NP * (KCH / 4) * (MI + NI) <= 12;     // fragment registers for a whole k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
@@ -588,12 +393,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
     *p.incr_counter = nv;
     if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
   }
-  if (p.epoch_bump && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) p.epoch_bump[0] += 1u;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r16 = lane & 15;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int M = p.M, N = p.N;
-  const int z = blockIdx.z, m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const E* A = (const E*)p.A + (size_t)z * p.a_batch_stride;
   const E* W = (const E*)p.W + (size_t)z * p.w_batch_stride;
   const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);   // bytes hi plane -> lo plane
@@ -719,8 +524,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += accl[mi][ni] * inv;
   }
-  if constexpr (LNX) gemm_epilogue_lnx<T, BM, BN, WM, WN>(p, acc, epre, m0, n0, wm, wn, g, r16, rowstat, smem);
-  else gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false>
@@ -747,68 +551,6 @@ static int gemm_tile_override() {
   static int v = [] { const char* e = getenv("FDM_GEMM_TILE"); return e ? atoi(e) : 0; }();
   return v;
 }
-
-// Row-group LayerNorm GEMMs (LNX): 1-D grid of ceil(row blocks / 8) * 8 * column tiles workgroups, all of which must be
-// resident for the in-launch exchange (bounded spins turn a violation into NaN outputs + *lnx_err, never a hang).  Residency
-// per CU = min(what the occupancy query admits, 2): the query is advisory, the cap keeps a margin.
-template <typename T, int BM, int BN, int WM, int WN, int NST>
-struct GemmLnx {
-  static constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * 128 + gemm_ln_scratch_bytes<BM, BN>();
-  static const void* fn() { return (const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, 8, false, false, true>; }
-  static int capacity() {
-    static int cap = [] {
-      static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
-      if (hipFuncSetAttribute(fn(), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 0;
-      int dev = 0, cus = 0, occ = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn(), 64 * WM * WN, lds) != hipSuccess) return 0;
-      return cus * (occ > 2 ? 2 : occ);
-    }();
-    return cap;
-  }
-  static hipError_t launch(const fdm_gemm_args& a, hipStream_t s) {
-    const int nrb = (a.M + BM - 1) / BM, nct = a.N / BN;
-    if (a.N % BN || nrb * nct > capacity()) return hipErrorCooperativeLaunchTooLarge;
-    hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, 8, false, false, true>), dim3(nct, nrb), dim3(64 * WM * WN), lds, s, a);
-    return hipGetLastError();
-  }
-};
-
-// op: 0 = launch, 1 = capacity query (returned through *cap, tile rows / columns through *bm / *bn)
-template <typename T>
-static hipError_t gemm_lnx_tile(int tile, int op, const fdm_gemm_args* a, hipStream_t s, int* cap, int* bm, int* bn) {
-  constexpr bool SPLIT = Opnd<T>::NP == 2;
-  auto run = [&](auto tag) -> hipError_t {
-    using G = decltype(tag);
-    if (op == 1) { *cap = G::capacity(); return hipSuccess; }
-    return G::launch(*a, s);
-  };
-  auto dims = [&](int m, int n) { if (bm) *bm = m; if (bn) *bn = n; };
-  switch (tile) {
-    case FDM_TILE_128x64: case FDM_TILE_128x64_S3:
-      dims(128, 64); return run(GemmLnx<T, 128, 64, 4, 2, SPLIT ? 3 : 4>{});
-    case FDM_TILE_128x128: case FDM_TILE_96x128: case FDM_TILE_256x128:
-      dims(128, 128); return run(GemmLnx<T, 128, 128, 2, 4, SPLIT ? 2 : 3>{});
-    case FDM_TILE_64x64_S2: dims(64, 64); return run(GemmLnx<T, 64, 64, 2, 4, 2>{});
-    case FDM_TILE_64x64_S3: dims(64, 64); return run(GemmLnx<T, 64, 64, 2, 4, 3>{});
-    case FDM_TILE_32x64_S3: dims(32, 64); return run(GemmLnx<T, 32, 64, 2, 2, 3>{});
-    default: dims(64, 64); return run(GemmLnx<T, 64, 64, 2, 4, 4>{});
-  }
-}
-// Default tile of an lnx GEMM (fdm_gemm_args.tile == 0): the smallest tile whose grid is resident.
-template <typename T>
-static hipError_t gemm_dispatch_lnx(const fdm_gemm_args& a, hipStream_t s) {
-  const int env = gemm_tile_override();
-  const int want = a.tile > 0 ? a.tile : env;
-  if (want > 0) return gemm_lnx_tile<T>(want, 0, &a, s, nullptr, nullptr, nullptr);
-  for (int tile : {FDM_TILE_64x64, FDM_TILE_64x64_S2, FDM_TILE_128x64, FDM_TILE_128x128}) {
-    int cap = 0, bm = 0, bn = 0;
-    (void)gemm_lnx_tile<T>(tile, 1, nullptr, s, &cap, &bm, &bn);
-    if (a.N % bn == 0 && (long long)((a.M + bm - 1) / bm) * (a.N / bn) <= cap) return gemm_lnx_tile<T>(tile, 0, &a, s, nullptr, nullptr, nullptr);
-  }
-  return hipErrorCooperativeLaunchTooLarge;
-}
-
 
 template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {

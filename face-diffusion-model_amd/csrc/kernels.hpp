@@ -10,10 +10,6 @@ hipError_t gemm_launch_f32(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_bf16(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_f16x3(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_bf16x3(const fdm_gemm_args& a, hipStream_t s);
-int gemm_lnx_capacity_f32(int tile, int* bm, int* bn);
-int gemm_lnx_capacity_bf16(int tile, int* bm, int* bn);
-int gemm_lnx_capacity_f16x3(int tile, int* bm, int* bn);
-int gemm_lnx_capacity_bf16x3(int tile, int* bm, int* bn);
 hipError_t attn_launch_f32(const fdm_attn_args& a, hipStream_t s);
 hipError_t attn_launch_bf16(const fdm_attn_args& a, hipStream_t s);
 hipError_t attn_launch_f16x3(const fdm_attn_args& a, hipStream_t s);
@@ -26,14 +22,6 @@ inline hipError_t gemm_launch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_F16X3: return gemm_launch_f16x3(a, s);
     case FDM_BF16X3: return gemm_launch_bf16x3(a, s);
     default: return gemm_launch_f32(a, s);
-  }
-}
-inline int gemm_lnx_capacity(int dtype, int tile, int* bm, int* bn) {
-  switch (dtype) {
-    case FDM_BF16: return gemm_lnx_capacity_bf16(tile, bm, bn);
-    case FDM_F16X3: return gemm_lnx_capacity_f16x3(tile, bm, bn);
-    case FDM_BF16X3: return gemm_lnx_capacity_bf16x3(tile, bm, bn);
-    default: return gemm_lnx_capacity_f32(tile, bm, bn);
   }
 }
 inline hipError_t attn_launch(const fdm_attn_args& a, hipStream_t s) {

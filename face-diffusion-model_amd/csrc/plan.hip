@@ -201,10 +201,6 @@ struct fdm_plan {
   std::vector<float*> TT;
   std::vector<const float*> Wv, bv, Wo, bo;
   bool fuse_ln3 = false;
-  int lnx_wanted = -1;                       // -1: FDM_FUSE_LNX (default on); 0 / 1: fdm_plan_set("lnx")
-  bool lnx = false;                          // this shape runs the LayerNorms inside the out-proj / FFN2 GEMMs (42 launches per step)
-  unsigned long long* lnx_slots = nullptr; int lnx_slot_rows = 0;
-  unsigned int* lnx_words = nullptr;         // [exchange epoch, timeouts]
   std::map<int, Fold> fold;                  // layer l (1 .. n_layers-1) reads norm3 of layer l-1; -1 = latent decoder
   float *slopes = nullptr, *pe = nullptr;
   float *c1 = nullptr, *c2 = nullptr, *sigma = nullptr, *sra = nullptr, *srm1 = nullptr;
@@ -263,7 +259,7 @@ Mat mat_rows(const fdm_plan* P, const Mat& m, size_t row0, size_t cols) {
 
 std::string shape_key(const fdm_plan* P) {
   char b[64];
-  snprintf(b, sizeof(b), "%d,%d,%d,%d,%d", P->R, P->M, P->L, P->rep, (int)P->lnx);
+  snprintf(b, sizeof(b), "%d,%d,%d,%d", P->R, P->M, P->L, P->rep);
   return b;
 }
 
@@ -507,28 +503,9 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   for (int l = 0; l < m.n_layers; ++l) FCK(dalloc_t(P, &P->C1[l], R * d, true));
   FCK(dalloc_t(P, &P->step, (size_t)4, true));
   FCK(dalloc_t(P, &P->seedbuf, (size_t)2, true));
-  P->lnx_slot_rows = (int)((R + 255) / 256 * 256);
-  FCK(dalloc_t(P, &P->lnx_slots, (size_t)2 * P->lnx_slot_rows * (d / 64) * 2, true));      // zeroed: tags start below every epoch
-  FCK(dalloc_t(P, &P->lnx_words, (size_t)4, true));
   if (!P->tseq) { P->tseq_cap = 1024; FCK(dalloc_t(P, &P->tseq, (size_t)P->tseq_cap, false)); }
   P->capB = B; P->capL = L; P->capRep = repc;
   return FDM_OK;
-}
-
-// Tiles of the row-group LayerNorm GEMMs (out-proj, FFN2: [R, d] outputs) whose whole grid is resident at this shape.
-const int kLnxTiles[] = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64, FDM_TILE_128x128};
-bool lnx_tile_fits(const fdm_plan* P, int tile) {
-  int bm = 0, bn = 0;
-  const int cap = fdm_op_gemm_lnx_capacity(P->dtype, tile, &bm, &bn);
-  return cap > 0 && P->m.d % bn == 0 && (long long)((P->R + bm - 1) / bm) * (P->m.d / bn) <= cap;
-}
-bool lnx_feasible(const fdm_plan* P) {
-  const char* env = getenv("FDM_FUSE_LNX");
-  const bool want = P->lnx_wanted >= 0 ? P->lnx_wanted != 0 : !(env && !strcmp(env, "0"));
-  if (!want || P->m.n_layers * 2 > 32 || P->m.d % 64 || P->m.d > 1024) return false;
-  for (int tile : {FDM_TILE_64x64, FDM_TILE_64x64_S2, FDM_TILE_128x64, FDM_TILE_128x128})      // the op layer's default order
-    if (lnx_tile_fits(P, tile)) return true;
-  return false;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -537,7 +514,7 @@ bool lnx_feasible(const fdm_plan* P) {
 int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
   const fdm_model_desc& m = P->m;
   const int d = m.d, M = P->M, R = P->R, L = P->L;
-  const bool both = P->dtype != FDM_F32, split = is_split(P->dtype), fuse = P->fuse_ln3 && !P->lnx;
+  const bool both = P->dtype != FDM_F32, split = is_split(P->dtype), fuse = P->fuse_ln3;
   int* step = P->step; int* tcur = P->step + 1;
   const float* none = nullptr; (void)none;
   const float *b = nullptr;
@@ -552,60 +529,12 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
     if (both) set_out_t(g, P->ht);
     g.batch = P->rep; g.out_batch_stride = (long long)M * d;
     g.incr_counter = step; g.incr_table = P->tseq;
-    if (P->lnx) g.epoch_bump = P->lnx_words;          // a new exchange epoch per pass: every tag of the previous pass is stale
     FCK(plan_gemm(P, "enc", g, stream));
   }
   const int BB = P->B * P->rep;
   const float eps = 1e-5f;
   const int np = d / 64;
-  auto set_lnx = [&](fdm_gemm_args& g, int site) {
-    g.lnx_slots = P->lnx_slots; g.lnx_slot_rows = P->lnx_slot_rows; g.lnx_epoch = P->lnx_words; g.lnx_err = P->lnx_words + 1;
-    g.lnx_site = site | (getenv("FDM_LNX_NOWAIT") ? atoi(getenv("FDM_LNX_NOWAIT")) : 0); g.ln_eps = eps;
-  };
-  for (int l = 0; P->lnx && l < m.n_layers; ++l) {
-    // LayerNorms inside the GEMMs that feed them (gemm.hpp, row-group LayerNorm epilogue): QKV, attention,
-    // out-proj -> norm1 + norm2, FFN1, FFN2 -> norm3
-    FCK(need(P, lname(l, "self_attn.in_proj_bias"), 3LL * d, &b));
-    fdm_gemm_args g = gemm_op(P, P->ht, P->wt[lname(l, "self_attn.in_proj_weight")], R, 3 * d, d);
-    g.bias = b;
-    const bool split_attn = P->dtype == FDM_F16X3;
-    if (split && !split_attn) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
-    else { g.out_t = P->q; g.ldo_t = d; g.out_t_lo_off = split_attn ? P->q_lo : 0; }
-    g.kv_lo_off = split_attn ? P->kv_lo : 0;
-    g.out_kp = P->kp; g.kp_col0 = d; g.out_vp = P->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = P->Lpad; g.kv_hd = P->hd;
-    FCK(plan_gemm(P, "qkv", g, stream));
-    fdm_attn_args at;
-    memset(&at, 0, sizeof(at));
-    at.Q = P->q; at.ldq = d; at.Kp = P->kp; at.Vp = P->vp; at.Lpad = P->Lpad; at.O = P->ctx.p; at.ldo = d;
-    at.B = BB; at.H = m.n_head; at.L = L; at.hd = P->hd; at.dtype = split_attn ? FDM_F16X3 : (split ? FDM_F32 : P->dtype);
-    at.scale = 1.0f / std::sqrt((float)P->hd); at.causal = 1; at.slopes = P->slopes; at.period = m.period;
-    if (split_attn) { at.q_lo_off = P->q_lo; at.kv_lo_off = P->kv_lo; at.o_lo_off = P->ctx.lo; }
-    else if (split) { at.o_split = P->dtype; at.o_lo_off = P->ctx.lo; }
-    FCK(fdm_op_attention(&at, stream));
-    // h2 = LN2(LN1(h + ctx Wo^T + bo) + C1_l + TT_l[t])
-    FCK(need(P, lname(l, "self_attn.out_proj.bias"), d, &b));
-    g = gemm_op(P, P->ctx, P->wt[lname(l, "self_attn.out_proj.weight")], R, d, d);
-    g.bias = b; g.resid = P->h; g.out_f32 = P->h2;
-    if (both) set_out_t(g, P->h2t);
-    FCK(need(P, lname(l, "norm1.weight"), d, &g.lnx_gamma)); FCK(need(P, lname(l, "norm1.bias"), d, &g.lnx_beta));
-    FCK(need(P, lname(l, "norm2.weight"), d, &g.lnx_gamma2)); FCK(need(P, lname(l, "norm2.bias"), d, &g.lnx_beta2));
-    g.lnx_add_mat = P->C1[l]; g.lnx_add_tab = P->TT[l]; g.lnx_tab_step = tcur;
-    set_lnx(g, 2 * l);
-    FCK(plan_gemm(P, "out_lnx", g, stream));
-    FCK(need(P, lname(l, "linear1.bias"), m.ffn, &b));
-    g = gemm_op(P, P->h2t, P->wt[lname(l, "linear1.weight")], R, m.ffn, d);
-    g.bias = b; g.act = FDM_ACT_RELU; set_out_t(g, P->u);
-    FCK(plan_gemm(P, "ffn1", g, stream));
-    // h = LN3(h2 + u W2^T + b2)
-    FCK(need(P, lname(l, "linear2.bias"), d, &b));
-    g = gemm_op(P, P->u, P->wt[lname(l, "linear2.weight")], R, d, m.ffn);
-    g.bias = b; g.resid = P->h2; g.out_f32 = P->h;
-    if (both) set_out_t(g, P->ht);
-    FCK(need(P, lname(l, "norm3.weight"), d, &g.lnx_gamma)); FCK(need(P, lname(l, "norm3.bias"), d, &g.lnx_beta));
-    set_lnx(g, 2 * l + 1);
-    FCK(plan_gemm(P, "ffn2_lnx", g, stream));
-  }
-  for (int l = 0; !P->lnx && l < m.n_layers; ++l) {
+  for (int l = 0; l < m.n_layers; ++l) {
     const Fold* f = (fuse && l > 0) ? &P->fold[l] : nullptr;
     fdm_gemm_args g;
     if (!f) {
@@ -917,13 +846,8 @@ int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
     FCK(timed(inst, 0, &base));
     std::vector<std::pair<float, int>> cand = {{base * 0.97f, 0}};          // switch only for a > 3 % gain over the heuristic
     double best_model = 1e30;
-    std::vector<int> site_cands = cands;
-    if (kv.second[0].lnx_gamma) {          // row-group LayerNorm sites: only tiles whose whole grid is resident
-      site_cands.clear();
-      for (int tile : kLnxTiles) if (lnx_tile_fits(P, tile)) site_cands.push_back(tile);
-    }
-    for (int tile : site_cands) best_model = std::min(best_model, modelled_us(kv.second[0], tile));
-    for (int tile : site_cands) {
+    for (int tile : cands) best_model = std::min(best_model, modelled_us(kv.second[0], tile));
+    for (int tile : cands) {
       if (modelled_us(kv.second[0], tile) > 1.35 * best_model) continue;
       float t = 0.f;
       FCK(timed(inst, tile, &t));
@@ -1061,7 +985,6 @@ int fdm_audio_prepare(fdm_plan* P, const float* hub, int B, int N, int fw, const
   hipStream_t s = (hipStream_t)stream;
   const int d = m.d, M = B * L, rep = cfg ? 2 : 1;
   P->B = B; P->L = L; P->M = M; P->rep = rep; P->R = M * rep; P->cfg = cfg ? 1 : 0; P->Lpad = (L + 31) / 32 * 32;
-  P->lnx = lnx_feasible(P);
   // pad keys of the packed K / V buffers must be finite: the layout depends on (L, Lpad), so clear them per shape
   HIPCK(hipMemsetAsync(P->kp, 0, P->kv_bytes, s));
   HIPCK(hipMemsetAsync(P->vp, 0, P->kv_bytes, s));
@@ -1212,13 +1135,7 @@ int fdm_plan_get(fdm_plan* P, const char* key, long long* out) {
   const std::string k(key);
   if (k == "launches_per_step") *out = P->launches_per_step;
   else if (k == "graph_launches") *out = P->last_graph_launches;
-  else if (k == "fuse_ln3") *out = P->fuse_ln3 && !P->lnx;
-  else if (k == "lnx") *out = P->lnx;
-  else if (k == "exchange_timeouts") {       // synchronises: waits of the in-GEMM LayerNorm exchange that hit their spin bound (0 in a healthy run)
-    unsigned int v = 0;
-    if (P->lnx_words) HIPCK(hipMemcpy(&v, P->lnx_words + 1, 4, hipMemcpyDeviceToHost));
-    *out = v;
-  }
+  else if (k == "fuse_ln3") *out = P->fuse_ln3;
   else if (k == "rows") *out = P->R;
   else if (k == "tuned") *out = P->tile_cache.count(shape_key(P)) ? 1 : 0;
   else if (k.rfind("tile.", 0) == 0) { auto it = P->tiles.find(k.substr(5)); *out = it == P->tiles.end() ? 0 : it->second; }
@@ -1230,16 +1147,6 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
   if (!P || !key) return fail(FDM_ERR_ARG, "plan_set: null argument");
   const std::string k(key);
   if (k == "tune") { P->tune_enabled = value != 0; return FDM_OK; }
-  if (k == "lnx") {         // LayerNorms inside the out-proj / FFN2 GEMMs on (1) / off (0) / FDM_FUSE_LNX (-1); applies at once
-    P->lnx_wanted = value < 0 ? -1 : (value != 0);
-    FCK(drop_programs(P, nullptr));
-    if (P->prepared) {
-      P->lnx = lnx_feasible(P);
-      auto it = P->tile_cache.find(shape_key(P));
-      P->tiles = it == P->tile_cache.end() ? std::map<std::string, int>() : it->second;
-    }
-    return FDM_OK;
-  }
   if (k == "untune") {      // forget the tuned tiles of every shape (tests)
     P->tile_cache.clear(); P->steps_seen.clear(); P->tiles.clear();
     return drop_programs(P, nullptr);

@@ -36,10 +36,7 @@ class GemmArgs(C.Structure):
                 ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
                 ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci),
                 ("sched_fuse", ci), ("sched", SchedArgs),
-                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll),
-                ("lnx_gamma", vp), ("lnx_beta", vp), ("lnx_gamma2", vp), ("lnx_beta2", vp), ("lnx_add_mat", vp),
-                ("lnx_add_tab", vp), ("lnx_tab_step", vp), ("lnx_slots", vp), ("lnx_slot_rows", ci),
-                ("lnx_epoch", vp), ("lnx_site", ci), ("lnx_err", vp), ("epoch_bump", vp)]
+                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll)]
 
 
 TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
@@ -77,7 +74,6 @@ SYMBOLS = {
     "fdm_version": (ci, []),
     "fdm_device_ok": (ci, []),
     "fdm_op_gemm": (ci, [C.POINTER(GemmArgs), vp]),
-    "fdm_op_gemm_lnx_capacity": (ci, [ci, ci, C.POINTER(ci), C.POINTER(ci)]),
     "fdm_op_attention": (ci, [C.POINTER(AttnArgs), vp]),
     "fdm_op_pack_kv": (ci, [vp, ll, vp, ll, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "fdm_op_layernorm": (ci, [C.POINTER(LnArgs), vp]),

@@ -21,7 +21,7 @@ import torch
 from . import presets, schedule
 from ._lib import F32, FdmError, ModelDesc, SampleArgs, check, lib
 
-TILE_SITES = ("enc", "qkv", "qkv_ln", "out", "out_ln", "out_lnx", "ffn1", "ffn2", "ffn2_stat", "ffn2_lnx", "dec", "dec_ln")
+TILE_SITES = ("enc", "qkv", "qkv_ln", "out", "out_ln", "ffn1", "ffn2", "ffn2_stat", "dec", "dec_ln")
 
 
 def _dev(t, device):
@@ -194,13 +194,3 @@ class DenoiserPlan:
     @property
     def fuse_ln3(self):
         return bool(self.get("fuse_ln3"))
-
-    @property
-    def lnx(self):
-        """True when this shape runs its LayerNorms inside the out-proj / FFN2 GEMMs (42 kernel launches per step)."""
-        return bool(self.get("lnx"))
-
-    @property
-    def exchange_timeouts(self):
-        """Waits of the in-GEMM LayerNorm exchange that hit their bound (synchronises; 0 in a healthy run)."""
-        return self.get("exchange_timeouts")

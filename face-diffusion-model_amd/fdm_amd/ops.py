@@ -88,7 +88,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
          out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
          out_kp=None, kp_col0=0, out_vp=None, vp_col0=0, kv_L=0, kv_Lpad=0, kv_hd=0,
          stat_out=None, ln_stat_in=None, ln_nparts=0, ln_dim=0, ln_eps=1e-5, ln_colsum=None, rln_gamma=None, rln_beta=None,
-         incr_counter=None, incr_table=None, tile=0, sched=None, lnx=None, epoch_bump=None):
+         incr_counter=None, incr_table=None, tile=0, sched=None):
     a = GemmArgs()
     a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
     a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
@@ -110,41 +110,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.tile = tile
     if sched is not None:      # fused scheduler update in the epilogue (resid = x_t, out_f32 = x_{t-1})
         a.sched_fuse, a.sched = 1, sched
-    if lnx is not None:        # LayerNorm(s) of the output rows inside the GEMM: see LnxState
-        st = lnx["state"]
-        a.lnx_gamma, a.lnx_beta = _p(lnx["gamma"]), _p(lnx["beta"])
-        a.lnx_gamma2, a.lnx_beta2 = _p(lnx.get("gamma2")), _p(lnx.get("beta2"))
-        a.lnx_add_mat, a.lnx_add_tab, a.lnx_tab_step = _p(lnx.get("add_mat")), _p(lnx.get("add_tab")), _p(lnx.get("tab_step"))
-        a.lnx_slots, a.lnx_slot_rows = _p(st.slots), st.slot_rows
-        a.lnx_epoch, a.lnx_err, a.lnx_site = st.words.data_ptr(), st.words.data_ptr() + 4, lnx.get("site", 0)
-    a.epoch_bump = _p(epoch_bump)
     check(lib().fdm_op_gemm(C.byref(a), stream()))
-
-
-class LnxState:
-    """Exchange state of the in-GEMM LayerNorm (fdm_gemm_args.lnx_*): tagged partial slots for up to `rows` rows of `d` columns,
-    and the [epoch, timeouts] words.  `bump()` starts a new epoch (inside a chain the first GEMM does it: epoch_bump)."""
-
-    def __init__(self, rows, d, device):
-        self.slot_rows = (rows + 255) // 256 * 256
-        self.slots = torch.zeros(2 * self.slot_rows * (d // 64) * 2, dtype=torch.int64, device=device)
-        self.words = torch.zeros(4, dtype=torch.int32, device=device)
-
-    def bump(self):
-        self.words[0] += 1
-
-    @property
-    def timeouts(self):
-        return int(self.words[1].item())
-
-
-def gemm_lnx_capacity(dtype, tile):
-    """(resident workgroups, tile rows, tile columns) of an lnx GEMM with this operand kind and tile."""
-    bm, bn = C.c_int(0), C.c_int(0)
-    cap = lib().fdm_op_gemm_lnx_capacity(dtype, tile, C.byref(bm), C.byref(bn))
-    if cap < 0:
-        check(cap)
-    return cap, bm.value, bn.value
 
 
 def kv_pad(L):

@@ -140,27 +140,6 @@ typedef struct fdm_gemm_args {
   /* split operand kinds (dtype FDM_F16X3 / FDM_BF16X3): elements between the hi and lo planes of A, W and out_t */
   long long a_lo_off, w_lo_off, out_t_lo_off;
   long long kv_lo_off;            /* FDM_F16X3 with out_kp / out_vp: elements between the hi and lo planes of the packed buffers */
-  /* --- LayerNorm of the output rows INSIDE the GEMM (the step's out-proj and FFN2 GEMMs; removes the LayerNorm launches) ---
-   * lnx_gamma != NULL: with x = acc + bias + resid (the usual epilogue value, act must be FDM_ACT_NONE),
-   *     y = LN(x; lnx_gamma, lnx_beta)                                                   (norm3, models/fdm_vocaset.py:45-51)
-   *  or y = LN(LN(x; lnx_gamma, lnx_beta) + lnx_add_mat[m] + lnx_add_tab[*lnx_tab_step]; lnx_gamma2, lnx_beta2)   (norm1 + norm2)
-   *   goes to out_f32 / out_t.  A row's N columns are spread over the N / BN column tiles of its row block; those workgroups
-   *   exchange per-64-column (sum, M2) partials through lnx_slots inside the launch, as 8-byte {tag, value} words written and
-   *   polled with relaxed agent-scope atomics (the data is the flag; no placement or dispatch-order assumption), combined in a
-   *   fixed order (Chan's formula): the statistics are those of a two-pass LayerNorm and do not depend on `tile`.
-   *   tag = *lnx_epoch * 32 + lnx_site: the first kernel of every pass over the chain advances the epoch (epoch_bump), so slots
-   *   are shared by all sites of a chain and never need re-zeroing.  Needs every workgroup of the launch resident
-   *   (fdm_op_gemm_lnx_capacity; refused otherwise), N % 64 == 0, N <= 1024, batch 1, 16-byte aligned outputs / resid.
-   *   A wait that exceeds its spin bound adds 1 to *lnx_err and poisons the block's outputs with NaN.                          */
-  const float* lnx_gamma; const float* lnx_beta;
-  const float* lnx_gamma2; const float* lnx_beta2;
-  const float* lnx_add_mat;       /* [M, N] fp32 or NULL */
-  const float* lnx_add_tab; const int* lnx_tab_step;   /* row *lnx_tab_step of a [rows, N] table, or NULL */
-  unsigned long long* lnx_slots;  /* 2 * lnx_slot_rows * (N / 64) * 2 words (zeroed once at allocation) */
-  int lnx_slot_rows;              /* >= M rounded up to a multiple of 256 */
-  const unsigned int* lnx_epoch; int lnx_site;         /* site < 32 */
-  unsigned int* lnx_err;
-  unsigned int* epoch_bump;       /* optional device word incremented once when the kernel starts (first kernel of a chain) */
 } fdm_gemm_args;
 #define FDM_TILE_AUTO 0
 #define FDM_TILE_64x64 1
@@ -174,9 +153,6 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_32x64_S3 9   /* 32x64 on 4 waves, 3-stage ring: twice the workgroups of 64x64 for few-hundred-row GEMMs */
 #define FDM_TILE_MAX 9
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
-/* Workgroups of an lnx GEMM (fdm_gemm_args.lnx_gamma) the device keeps resident at once with output tile `tile` and operand
- * kind `dtype`; the launch needs ceil(M / BM) * (N / BN) <= this.  *bm / *bn (optional) receive the tile's rows / columns. */
-int fdm_op_gemm_lnx_capacity(int dtype, int tile, int* bm, int* bn);
 
 /* ------------------------------------------------------------------------------------------
  * Fused softmax(Q K^T * scale + bias) V for one [B, H, L, hd] problem.

@@ -537,61 +537,3 @@ def test_gemm_fused_scheduler_equals_gemm_then_sched_step(dtype, mode):
         ops.gemm(A, W, M, d, K, bias=bias, resid=xf, out_f32=xf, out_t=xf_t, sched=ops.sched_args(mode, None, None, None, M * d, **kw))
         torch.cuda.synchronize()
         assert torch.equal(xf, ref) and torch.equal(xf_t, ref_t), (mode, k)
-
-
-@pytest.mark.parametrize("dtype,tol", [(F32, 2e-5), (F16X3, 2e-5), (BF16, 2e-2)])
-@pytest.mark.parametrize("M,N,K", [(301, 1024, 1024), (800, 1024, 2048), (2400, 512, 512), (40, 256, 512)])
-def test_gemm_row_layernorm_epilogue(dtype, tol, M, N, K):
-    """LayerNorm(s) of the output rows inside the GEMM (fdm_gemm_args.lnx_*): norm3 form y = LN(x) and the norm1 + norm2 form
-    y = LN2(LN1(x) + add_mat + add_tab[t]) with x = A W^T + bias + resid, against torch; the statistics are exchanged between
-    the column tiles of a row block inside the launch, and the result must not depend on the tile."""
-    g = torch.Generator().manual_seed(M + N + K)
-    A32 = torch.randn(M, K, generator=g)
-    W32 = torch.randn(N, K, generator=g) / math.sqrt(K)
-    A, W = ops.to_operand(A32.to(DEV), dtype), ops.to_operand(W32.to(DEV), dtype)
-    Ar, Wr = (A.float().cpu(), W.float().cpu()) if dtype != F32 else (A32, W32)
-    bias = torch.randn(N, generator=g)
-    resid = torch.randn(M, N, generator=g) * 2
-    am = torch.randn(M, N, generator=g)
-    tab = torch.randn(5, N, generator=g)
-    g1, b1, g2, b2 = [torch.randn(N, generator=g) * 0.1 + (1 if i % 2 == 0 else 0) for i in range(4)]
-    x = Ar.double() @ Wr.double().t() + bias.double() + resid.double()
-    ref1 = F.layer_norm(x, (N,), g1.double(), b1.double(), 1e-5)
-    ref2 = F.layer_norm(ref1 + am.double() + tab[3].double(), (N,), g2.double(), b2.double(), 1e-5)
-    st = ops.LnxState(M, N, DEV)
-    tstep = torch.tensor([3], dtype=torch.int32, device=DEV)
-    dv = lambda t: t.to(DEV)
-    outs = {}
-    for tile in (1, 8, 2, 3):
-        cap, bm, bn = ops.gemm_lnx_capacity(dtype, tile)
-        if N % bn or -(-M // bm) * (N // bn) > cap:
-            continue
-        for two in (False, True):
-            o32 = torch.zeros(M, N, device=DEV)
-            ot = None if dtype == F32 else (ops.Split.empty(M, N, dtype, DEV) if ops.is_split(dtype) else torch.zeros(M, N, device=DEV, dtype=torch.bfloat16))
-            lnx = dict(state=st, gamma=dv(g1), beta=dv(b1), site=5)
-            if two:
-                lnx.update(gamma2=dv(g2), beta2=dv(b2), add_mat=dv(am), add_tab=dv(tab), tab_step=tstep)
-            st.bump()
-            ops.gemm(A, W, M, N, K, bias=dv(bias), resid=dv(resid), out_f32=o32, out_t=ot, tile=tile, lnx=lnx)
-            torch.cuda.synchronize()
-            ref = ref2 if two else ref1
-            assert rel(o32, ref) < tol, (tile, two)
-            if ot is not None:
-                assert rel(ot.float(), ref) < max(tol, 1e-2 if dtype == BF16 else tol)
-            outs.setdefault(two, []).append(o32.clone())
-    assert st.timeouts == 0
-    for two, lst in outs.items():
-        assert len(lst) >= 2
-        for o in lst[1:]:
-            assert torch.equal(o, lst[0])       # tile choice changes speed, not results
-
-
-def test_gemm_row_layernorm_refuses_oversized_launch():
-    from fdm_amd._lib import FdmError
-    M, N, K = 20000, 1024, 256
-    A, W = torch.zeros(M, K, device=DEV), torch.zeros(N, K, device=DEV)
-    st = ops.LnxState(M, N, DEV)
-    one = torch.ones(N, device=DEV)
-    with pytest.raises(FdmError, match="resident"):
-        ops.gemm(A, W, M, N, K, out_f32=torch.zeros(M, N, device=DEV), lnx=dict(state=st, gamma=one, beta=one))
