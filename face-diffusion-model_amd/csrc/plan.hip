@@ -211,6 +211,7 @@ struct fdm_plan {
   float *h = nullptr, *h2 = nullptr, *x1 = nullptr, *x0 = nullptr, *x = nullptr, *x2 = nullptr, *stats = nullptr;
   Mat xt, ht, h2t, x2t, ctx, u;
   void *q = nullptr, *kp = nullptr, *vp = nullptr;
+  float* qkv32 = nullptr;                    // FDM_F16X3 at head_dim 256: fp32 Q | K | V rows of the QKV projection (attention runs in fp32)
   long long q_lo = 0, kv_lo = 0;             // FDM_F16X3: plane distances of q and of the packed K / V buffers
   size_t kv_bytes = 0;
   float *AF = nullptr, *t1 = nullptr, *sty = nullptr, *em = nullptr, *emu = nullptr, *zeros = nullptr, *E0 = nullptr;
@@ -490,6 +491,7 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   FCK(dalloc(P, &P->q, R * d * ea, true));
   FCK(dalloc(P, &P->kp, (size_t)B * repc * Lpad * d * ea, true));
   FCK(dalloc(P, &P->vp, (size_t)B * repc * Lpad * d * ea, true));
+  if (P->dtype == FDM_F16X3 && P->hd == 256) FCK(dalloc_t(P, &P->qkv32, R * 3 * d, true));
   P->q_lo = (long long)(R * d);
   P->kv_lo = (long long)((size_t)B * repc * Lpad * d);
   P->kv_bytes = (size_t)B * repc * Lpad * d * ea;
@@ -545,15 +547,24 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
       g = gemm_op(P, P->x2t, f->w, R, 3 * d, d);
       g.bias = f->bias; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.ln_colsum = f->colsum;
     }
-    const bool split_attn = P->dtype == FDM_F16X3;       // FDM_BF16X3 (comparison mode) keeps the fp32 attention kernel
-    if (split && !split_attn) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
+    // FDM_F16X3: split attention on plane pairs (head_dim 64 / 128).  At head_dim 256 (BIWI) the split kernel's fragments do
+    // not fit the register file: the projection writes fp32 rows, fdm_op_pack_kv lays K / V out for the fp32 attention
+    // kernel (one launch more per layer), whose output returns as a plane pair.  FDM_BF16X3 (comparison mode): fp32 attention.
+    const bool kv32 = P->qkv32 != nullptr;
+    const bool split_attn = P->dtype == FDM_F16X3 && !kv32;
+    if (kv32) { g.out_f32 = P->qkv32; g.ldo_f32 = 3 * d; }
+    else if (split && !split_attn) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
     else { g.out_t = P->q; g.ldo_t = d; g.out_t_lo_off = split_attn ? P->q_lo : 0; }
-    g.kv_lo_off = split_attn ? P->kv_lo : 0;
-    g.out_kp = P->kp; g.kp_col0 = d; g.out_vp = P->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = P->Lpad; g.kv_hd = P->hd;
+    if (!kv32) {
+      g.kv_lo_off = split_attn ? P->kv_lo : 0;
+      g.out_kp = P->kp; g.kp_col0 = d; g.out_vp = P->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = P->Lpad; g.kv_hd = P->hd;
+    }
     FCK(plan_gemm(P, f ? "qkv_ln" : "qkv", g, stream));
+    if (kv32) FCK(fdm_op_pack_kv(P->qkv32 + d, 3 * d, P->qkv32 + 2 * d, 3 * d, P->kp, P->vp, BB, m.n_head, L, P->Lpad, P->hd, FDM_F32, stream));
     fdm_attn_args at;
     memset(&at, 0, sizeof(at));
-    at.Q = P->q; at.ldq = d; at.Kp = P->kp; at.Vp = P->vp; at.Lpad = P->Lpad; at.O = P->ctx.p; at.ldo = d;
+    at.Q = kv32 ? (void*)P->qkv32 : P->q; at.ldq = kv32 ? 3 * d : d;
+    at.Kp = P->kp; at.Vp = P->vp; at.Lpad = P->Lpad; at.O = P->ctx.p; at.ldo = d;
     at.B = BB; at.H = m.n_head; at.L = L; at.hd = P->hd; at.dtype = split_attn ? FDM_F16X3 : (split ? FDM_F32 : P->dtype);
     at.scale = 1.0f / std::sqrt((float)P->hd); at.causal = 1; at.slopes = P->slopes; at.period = m.period;
     if (split_attn) { at.q_lo_off = P->q_lo; at.kv_lo_off = P->kv_lo; at.o_lo_off = P->ctx.lo; }
@@ -922,7 +933,6 @@ int fdm_plan_create(const fdm_model_desc* desc, int B, int L, int cfg, int dtype
   const int hd = m.d / m.n_head;
   if (hd != 64 && hd != 128 && hd != 256) return fail(FDM_ERR_SHAPE, "plan_create: head_dim %d unsupported (64, 128, 256)", hd);
   if (m.d != 256 && m.d != 512 && m.d != 768 && m.d != 1024) return fail(FDM_ERR_SHAPE, "plan_create: feature_dim %d unsupported (256, 512, 768, 1024)", m.d);
-  if (dtype == FDM_F16X3 && hd == 256) return fail(FDM_ERR_SHAPE, "plan_create: FDM_F16X3 supports head_dim 64 / 128 (split attention); use FDM_F32 for head_dim 256");
   if (B < 1 || L < 1 || L > m.max_len) return fail(FDM_ERR_SHAPE, "plan_create: B=%d, L=%d outside [1, .] x [1, %d] (models/fdm_vocaset.py:44)", B, L, m.max_len);
   if (!fdm_device_ok()) return fail(FDM_ERR_STATE, "plan_create: no gfx950 device visible (there is no CPU fallback)");
   fdm_plan* P = new (std::nothrow) fdm_plan();

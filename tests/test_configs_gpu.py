@@ -54,13 +54,14 @@ def test_cfg3_mead_full_chain_with_guidance(dtype):
     assert torch.equal(one[0], a[2]), "clip result depends on the batch it was sampled in"
 
 
-def test_cfg4_biwi_full_ddim_chain():
+@pytest.mark.parametrize("dtype", [F32, F16X3])
+def test_cfg4_biwi_full_ddim_chain(dtype):
     from test_denoiser_gpu import _biwi_oracle_clip
     preset, B, L, steps = "biwi", 4, 200, 250
     w = W.make_fdm_weights(preset)
     inp = W.synth_inputs(preset, B, L, seed=8)
     hub = torch.randn(B, 2 * L, 768, generator=torch.Generator().manual_seed(3))      # wav2vec2-base features
-    plan = DenoiserPlan(preset, w, F32, DEV)
+    plan = DenoiserPlan(preset, w, dtype, DEV)
     assert plan.p.head_dim == 256
     plan.prepare(hub, inp["style"], L=L)
     xT = inp["x"].to(DEV)

@@ -160,13 +160,15 @@ def test_long_chain_bf16_stays_close_to_fp32():
     assert mad(outs[F32], outs[BF16]) < 0.15
 
 
-def test_biwi_build_defined_semantics_vs_oracle():
+@pytest.mark.parametrize("dtype", PARITY_MODES)
+def test_biwi_build_defined_semantics_vs_oracle(dtype):
     """BIWI denoiser (models/fdm.py is unrunnable as shipped): build-defined 'Dec' struct with the
     latent regrouped x8, style Mish, plain-Linear latent encoder, period-25 ALiBi.  Parity is pinned against the
-    oracle restatement only (NOT against the reference)."""
+    oracle restatement only (NOT against the reference).  head_dim 256: the split mode projects Q / K / V to fp32 rows and
+    runs the fp32 attention kernel (plan.hip, record_chain)."""
     preset = "biwi"
     w = W.make_fdm_weights(preset)
-    plan = DenoiserPlan(preset, w, F32, DEV)
+    plan = DenoiserPlan(preset, w, dtype, DEV)
     B, L, t = 2, 33, 412
     inp = W.synth_inputs(preset, B, L, seed=8)
     hub = torch.randn(B, 2 * L, 768, generator=torch.Generator().manual_seed(3))      # wav2vec2-base features
