@@ -16,6 +16,7 @@
 //  * Epilogue is fused: bias, activation, residual add, dual-dtype stores, transposed "V^T" scatter.
 #pragma once
 #include <cstdlib>
+#include <cstring>
 
 #include "common.hpp"
 #include "sched.hpp"
@@ -120,11 +121,19 @@ template <bool HEAVY, typename T> __device__ __forceinline__ float gemm_act(floa
 }
 __host__ __device__ inline bool gemm_act_is_heavy(int act) { return act == ACT_MISH || act == ACT_GELU_ERF || act == ACT_GELU_TANH; }
 
-template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true, bool SCHED = false>
+// LEAN = every tile of the launch takes the straight-line path (the host checked it: gemm_all_tiles_lean), so the general
+// edge-handling path -- two thirds of the kernel's instructions, never executed by the step's GEMMs but in the way of the
+// instruction fetch -- is not compiled in.
+// SPEC further says what the launch can need: GEMM_KV = packed K / V outputs, GEMM_FOLD = the LayerNorm-folding producer /
+// consumer forms; a lean kernel without either is bias + activation + residual + stores (a few hundred instructions).
+constexpr int GEMM_LEAN = 1, GEMM_KV = 2, GEMM_FOLD = 4;
+template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true, bool SCHED = false, int SPEC = 0>
 __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               const EpiPre<BM / WM / 16, BN / WN / 16>& e, int m0, int n0, int z,
                                               int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  constexpr bool LEAN = (SPEC & GEMM_LEAN) != 0;
+  constexpr bool KVC = !LEAN || (SPEC & GEMM_KV), FOLDC = !LEAN || (SPEC & GEMM_FOLD);     // capabilities compiled in
   using E = typename Opnd<T>::E;      // element type of out_t (split kinds: two planes of it)
   using KK = typename Opnd<T>::KV;    // operand kind of the packed K / V outputs (a plane pair for f16x3)
   using KV = typename Opnd<KK>::E;    // their element type
@@ -134,11 +143,11 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   // store 16-byte runs of consecutive keys (one packed chunk each).  Needs the tile to lie entirely in the V columns
   // and clip boundaries on 16-byte multiples (L % (16 / sizeof(KV)) == 0); otherwise the per-element scatter is used.
   constexpr int EPC_T = 16 / (int)sizeof(KV);
-  const bool vt_tile = tile_lds && p.out_vp && n0 >= p.vp_col0 && n0 + BN <= N && (p.kv_L % EPC_T == 0);
+  const bool vt_tile = KVC && tile_lds && p.out_vp && n0 >= p.vp_col0 && n0 + BN <= N && (p.kv_L % EPC_T == 0);
   KV* tl = (KV*)tile_lds;
   float* comb = tile_lds ? (float*)(tile_lds + BM * BN * (int)sizeof(KV) * KNP) : nullptr;
-  const bool use_ln = rowstat && p.ln_stat_in;
-  const bool do_stat = rowstat && comb && p.stat_out;
+  const bool use_ln = FOLDC && rowstat && p.ln_stat_in;
+  const bool do_stat = FOLDC && rowstat && comb && p.stat_out;
   if (vt_tile || do_stat) __syncthreads();      // every wave is done reading the last ring stage
   // ---- fused epilogue: lane owns C[m = .. + r16][n = .. + 4g + (0..3)] ----
   const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
@@ -157,12 +166,12 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   // lean straight-line path.  The general path below handles every edge case but is ~1000 instructions of branches per
   // fragment: measured, the epilogue's code size IS the kernel's fixed cost (~0.3 us per 1000 lines of ISA on top of the
   // launch floor: 4.5 us for this 64x64 kernel, 16 us for a 128x128 tile on 4 waves), so the common case must be short.
-  const int kv_mode = (!p.out_kp && !p.out_vp) ? 0
+  const int kv_mode = (!KVC || (!p.out_kp && !p.out_vp)) ? 0
                     : (n0 + BN <= (p.out_kp ? kcol_lo : p.vp_col0)) ? 0
                     : (p.out_kp && n0 >= kcol_lo && n0 + BN <= kcol_hi) ? 1
                     : vt_tile ? 2 : -1;
-  const bool lean = kv_mode >= 0 && n0 + BN <= N && (vec_f32 || !p.out_f32) && (vec_t || !p.out_t) && (vec_r || !p.resid) &&
-                    (p.kv_hd % 16 == 0 || kv_mode != 1);
+  const bool lean = LEAN || (kv_mode >= 0 && n0 + BN <= N && (vec_f32 || !p.out_f32) && (vec_t || !p.out_t) && (vec_r || !p.resid) &&
+                            (p.kv_hd % 16 == 0 || kv_mode != 1));
   if (lean) {
     const int ncol = n0 + wn * (BN / WN) + 4 * g;            // this lane's column in fragment ni = 0
     const int KH = (kv_mode == 1) ? (kcol_hi - kcol_lo) / p.kv_hd : 1;
@@ -217,7 +226,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         if (ot) store_opnd4<T>(ot + ni * 16, p.out_t_lo_off, v);
       }
     }
-  } else {
+  } else if constexpr (!LEAN) {
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int lrow = wm * (BM / WM) + mi * 16 + r16;
@@ -369,7 +378,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
   using E = typename Opnd<T>::E;
@@ -385,6 +394,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   static_assert(NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>(), "epilogue staging does not fit in the ring");
   constexpr bool EARLY_READS = NP * (KCH / 4) * (MI + NI) <= 12;     // fragment registers for a whole k-tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef FDM_GEMM_STAMPS
+  const unsigned long long t_first = wall_clock64();      // before any kernel argument is read
+#endif
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -393,6 +405,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
     *p.incr_counter = nv;
     if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
   }
+#ifdef FDM_GEMM_STAMPS
+  unsigned long long* stamps = (!p.incr_counter && p.incr_table) ? (unsigned long long*)p.incr_table + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  if (stamps && tid == 0) { stamps[0] = wall_clock64(); stamps[5] = t_first; }
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r16 = lane & 15;
@@ -442,15 +458,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
       if constexpr (NP == 2) accl[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-  EpiPre<MI, NI> epre;       // epilogue operands: issued before (= older than) every ring load
-  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, true, epre);
-
+  // The first ring tiles are requested before anything else that touches memory (the first k-tile's latency is the longest
+  // wait of the kernel); the epilogue operands follow, younger than those tiles and older than every later one: the counted
+  // waits of the first k iterations are stricter by their number until they have returned, and the loop's final vmcnt(0)
+  // covers them in any case.
   constexpr int EPC = 16 / (int)sizeof(E);
   const int nk = p.K / (KCH * EPC);
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) issue(t);
-  gemm_load_rowstats<BM>(p, m0, rowstat);   // visible to every wave after the first barrier of the k loop
+  EpiPre<MI, NI> epre;
+  constexpr bool FOLDC = !(SPEC & GEMM_LEAN) || (SPEC & GEMM_FOLD);
+  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
+  if constexpr (FOLDC) gemm_load_rowstats<BM>(p, m0, rowstat);   // visible to every wave after the first barrier of the k loop
 
   // fragment (plane pl, k-step s) of tile row `row` in the stage at `base`: one ds_read_b128 through the XOR swizzle
   auto frag_a = [&](const char* base, int pl, int s, int mi) {
@@ -476,6 +496,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
     if (kt + NST - 2 < nk) wait_vmcnt<(NST - 2) * P>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();           // everyone's part of tile kt landed; stage (kt-1)%NST is free
+#ifdef FDM_GEMM_STAMPS
+    if (stamps && tid == 0 && kt == 0) stamps[1] = wall_clock64();
+#endif
     const char* base = smem + (kt % NST) * STAGE;
     if constexpr (EARLY_READS) {
       // fragment reads first, THEN the LDS-DMA issue for tile kt+NST-1: a DMA piece costs the issuing wave 60-180
@@ -524,25 +547,67 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += accl[mi][ni] * inv;
   }
-  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+#ifdef FDM_GEMM_STAMPS
+  if (stamps && tid == 0) stamps[2] = wall_clock64();
+#endif
+  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+#ifdef FDM_GEMM_STAMPS
+  if (stamps && tid == 0) stamps[3] = wall_clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (stamps && tid == 0) stamps[4] = wall_clock64();
+#endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false, int SPEC = 0>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
   constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
   static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
   static bool once = [] {
-    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED>), grid, dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC>), grid, dim3(64 * WM * WN), lds, s, a);
   return hipGetLastError();
+}
+// Host mirror of the epilogue's `lean` predicate for EVERY tile of the launch: interior column tiles, vectorisable outputs /
+// residual, and (QKV projections) tile-aligned Q | K | V column ranges with whole packed chunks.
+template <typename T, int BM, int BN>
+static bool gemm_all_tiles_lean(const fdm_gemm_args& a) {
+  using E = typename Opnd<T>::E;
+  using KK = typename Opnd<T>::KV;
+  using KV = typename Opnd<KK>::E;
+  auto al = [](const void* p, size_t n) { return ((uintptr_t)p % n) == 0; };
+  if (a.N % BN || a.out_batch_stride % 4 || a.resid_row_mod) return false;
+  if (a.out_f32 && (a.ldo_f32 % 4 || !al(a.out_f32, 16))) return false;
+  if (a.out_t && (a.ldo_t % 4 || !al(a.out_t, 4 * sizeof(E)) || (Opnd<T>::NP == 2 && a.out_t_lo_off % 4))) return false;
+  if (a.resid && (a.ldr % 4 || !al(a.resid, 16))) return false;
+  if (a.out_kp || a.out_vp) {
+    const int kcol_lo = a.out_kp ? a.kp_col0 : a.N, kcol_hi = a.out_kp ? (a.out_vp ? a.vp_col0 : a.N) : a.N;
+    if (a.kv_hd % 16) return false;
+    if (a.out_kp && (kcol_lo % BN || kcol_hi % BN)) return false;
+    if (a.out_vp && (a.vp_col0 % BN || a.kv_L % (16 / (int)sizeof(KV)))) return false;
+    if (!a.out_kp && a.out_vp) return false;          // (V-only projections: the general kernel)
+  }
+  return true;
 }
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
 static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
-  return gemm_act_is_heavy(a.act) ? gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true>(a, s)
-                                  : gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false>(a, s);
+  static const bool no_lean = getenv("FDM_GEMM_LEAN") && !strcmp(getenv("FDM_GEMM_LEAN"), "0");
+  if (gemm_act_is_heavy(a.act)) {
+    if (!no_lean && !a.out_kp && !a.out_vp && !a.stat_out && !a.ln_stat_in && gemm_all_tiles_lean<T, BM, BN>(a))
+      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_LEAN>(a, s);
+    return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true>(a, s);
+  }
+  if (!no_lean && gemm_all_tiles_lean<T, BM, BN>(a)) {
+    const bool kv = a.out_kp || a.out_vp, fold = a.stat_out || a.ln_stat_in;
+    if (kv && fold) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KV | GEMM_FOLD>(a, s);
+    if (kv) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KV>(a, s);
+    if (fold) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_FOLD>(a, s);
+    return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN>(a, s);
+  }
+  return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false>(a, s);
 }
 
 // Tile choice: fdm_gemm_args.tile (the caller's plan-time choice), else the FDM_GEMM_TILE override (env, read once: the
@@ -556,7 +621,9 @@ template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   const long long batch = a.batch > 0 ? a.batch : 1;
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
-  if (a.sched_fuse) return gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true>(a, s);    // (validated: interior tiles only)
+  if (a.sched_fuse)       // (validated: interior tiles only -> the lean epilogue)
+    return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
+                        : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
   switch (a.tile > 0 ? a.tile : gemm_tile_override()) {
     case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);      // 8 waves, 32x16 per wave
     case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
@@ -584,7 +651,9 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
 template <typename T>
 static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
   const long long batch = a.batch > 0 ? a.batch : 1;
-  if (a.sched_fuse) return gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true>(a, s);
+  if (a.sched_fuse)
+    return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
+                        : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
   if constexpr (std::is_same<T, bf16x3_t>::value) {
     return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                          // comparison mode: one tile
   } else {
