@@ -23,18 +23,23 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = blockIdx.x, col = tid * 4;
   const bool two = p.gamma2 != nullptr;
+  // every load of the kernel is requested before the first value is used: the row, the matrix addend and the affine vectors
+  // go out at once, the table row one dependent scalar load (the device-side step word) later -- one memory latency in
+  // all instead of one per operand (the kernel is launch-to-launch latency, not bandwidth)
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 v = *(const f32x4*)(p.x + (size_t)row * d + col);
-  f32x4 e = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool has_e = p.add_mat || p.add_tab;
-  if (p.add_mat) e = *(const f32x4*)(p.add_mat + (size_t)row * d + col);
+  const f32x4 em = p.add_mat ? *(const f32x4*)(p.add_mat + (size_t)row * d + col) : zero;
+  const f32x4 g1 = *(const f32x4*)(p.gamma + col), b1 = *(const f32x4*)(p.beta + col);
+  const float *gp2 = two ? p.gamma2 : p.gamma, *bp2 = two ? p.beta2 : p.beta;      // (a select of pointers, not of loaded data)
+  const f32x4 g2 = *(const f32x4*)(gp2 + col), b2 = *(const f32x4*)(bp2 + col);
+  f32x4 et = zero;
   if (p.add_tab) {
     const int k = p.tab_step ? *p.tab_step : 0;
     const int idx = p.tab_index ? p.tab_index[k] : k;
-    e += *(const f32x4*)(p.add_tab + (size_t)idx * d + col);
+    et = *(const f32x4*)(p.add_tab + (size_t)idx * d + col);
   }
-  const f32x4 g1 = *(const f32x4*)(p.gamma + col), b1 = *(const f32x4*)(p.beta + col);
-  f32x4 g2 = g1, b2 = b1;
-  if (two) { g2 = *(const f32x4*)(p.gamma2 + col); b2 = *(const f32x4*)(p.beta2 + col); }
+  const f32x4 e = p.add_tab ? em + et : em;
   auto block_sum = [&](float x, int slot) {
     x = wave_sum(x);
     if (lane == 0) red[slot][wave] = x;
