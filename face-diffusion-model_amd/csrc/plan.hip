@@ -390,11 +390,12 @@ int commit(fdm_plan* P, void* stream) {
     g.out_f32 = P->TT[l];
     FCK(fdm_op_gemm(&g, stream));
   }
-  // bf16 step program: norm3 of layer l-1 folded into the QKV / out-proj GEMMs of layer l and into the latent decoder
-  //   LN(x) W^T + b = rstd (x W'^T - mu colsum(W')) + (W beta + b),  W' = W o gamma
+  // Optional (FDM_FUSE_LN3=1; bf16 and f16x3): norm3 of layer l-1 folded into the QKV / out-proj GEMMs of layer l and into the
+  // latent decoder,   LN(x) W^T + b = rstd (x W'^T - mu colsum(W')) + (W beta + b),  W' = W o gamma   -- 8 launches fewer.
+  // Off by default since the GEMM kernels were specialised: the plain GEMM + LayerNorm launch is now as fast or faster than
+  // the three GEMMs that carry the fold (profiles/README.md, A/B of the final build).
   const char* env = getenv("FDM_FUSE_LN3");
-  // (default on in bf16; f16x3: opt-in with FDM_FUSE_LN3=1 -- same algebra on the plane pairs)
-  P->fuse_ln3 = (P->dtype == FDM_BF16 && !(env && !strcmp(env, "0"))) || (P->dtype == FDM_F16X3 && env && !strcmp(env, "1"));
+  P->fuse_ln3 = (P->dtype == FDM_BF16 || P->dtype == FDM_F16X3) && env && !strcmp(env, "1");
   if (P->fuse_ln3) {
     auto make_fold = [&](const std::string& wname, const std::string& bname, int N, int l_prev, Fold* f) -> int {
       const float *W = nullptr, *b = nullptr, *gam = nullptr, *bet = nullptr;

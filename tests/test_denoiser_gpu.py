@@ -221,11 +221,13 @@ def test_bf16_folded_norm3_matches_unfolded(monkeypatch):
     ref = FO.fdm_forward(w, "vocaset", inp["hub"], t, inp["x"], inp["style"], None, folded=True)
     assert mad(outs["1"], ref) < TOLBF and mad(outs["0"], ref) < TOLBF
     assert mad(outs["1"], outs["0"]) < TOLBF
+    monkeypatch.delenv("FDM_FUSE_LN3")
+    assert DenoiserPlan("vocaset", w, BF16, DEV).fuse_ln3 is False       # opt-in since the specialised GEMM kernels
 
 
 def test_f16x3_folded_norm3_is_opt_in_and_stays_in_contract(monkeypatch):
     """FDM_FUSE_LN3=1 folds norm3 into the surrounding GEMMs in the split-fp16 program too (the same algebra on plane pairs:
-    8 launches fewer, ~1 % faster -- off by default): still inside the 1e-4 contract of the reference goldens."""
+    8 launches fewer -- off by default): still inside the 1e-4 contract of the reference goldens."""
     L, t = 50, 777
     inp = W.synth_inputs("vocaset", 2, L, seed=31)
     w = W.make_fdm_weights("vocaset")
