@@ -169,7 +169,8 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   const int kv_mode = (!KVC || (!p.out_kp && !p.out_vp)) ? 0
                     : (n0 + BN <= (p.out_kp ? kcol_lo : p.vp_col0)) ? 0
                     : (p.out_kp && n0 >= kcol_lo && n0 + BN <= kcol_hi) ? 1
-                    : vt_tile ? 2 : -1;
+                    : vt_tile ? 2
+                    : (p.out_vp && n0 >= p.vp_col0 && n0 + BN <= N) ? 3 : -1;      // 3: V columns, clip length not in whole packed chunks
   const bool lean = LEAN || (kv_mode >= 0 && n0 + BN <= N && (vec_f32 || !p.out_f32) && (vec_t || !p.out_t) && (vec_r || !p.resid) &&
                             (p.kv_hd % 16 == 0 || kv_mode != 1));
   if (lean) {
@@ -189,6 +190,10 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         const int kv_b = m / p.kv_L;
         kv_l = m - kv_b * p.kv_L;
         okp = (KV*)p.out_kp + (size_t)kv_b * KH * kv_blk;
+      } else if (kv_mode == 3) {
+        const int kv_b = m / p.kv_L;
+        kv_l = m - kv_b * p.kv_L;
+        okp = (KV*)p.out_vp + (size_t)kv_b * kv_H * kv_blk;
       }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) {
@@ -220,6 +225,13 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
           const int cc = ncol + ni * 16 - kcol_lo;
           const int h = cc / p.kv_hd, e2 = cc - h * p.kv_hd;
           store_opnd4<KK>(okp + (size_t)h * kv_blk + kp_offset<KV>(kv_l, e2, p.kv_hd), p.kv_lo_off, v);
+          continue;
+        }
+        if (kv_mode == 3) {       // per-element scatter into the packed V^T layout (the lane's 4 columns share a head: kv_hd % 16 == 0)
+          const int cc = ncol + ni * 16 - p.vp_col0;
+          const int h = cc / p.kv_hd, e2 = cc - h * p.kv_hd;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) store_opnd1<KK>(okp + (size_t)h * kv_blk + vp_offset<KV>(kv_l, e2 + j, p.kv_hd), p.kv_lo_off, v[j]);
           continue;
         }
         if (o32) *(f32x4*)(o32 + ni * 16) = v;
@@ -576,8 +588,6 @@ static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
 template <typename T, int BM, int BN>
 static bool gemm_all_tiles_lean(const fdm_gemm_args& a) {
   using E = typename Opnd<T>::E;
-  using KK = typename Opnd<T>::KV;
-  using KV = typename Opnd<KK>::E;
   auto al = [](const void* p, size_t n) { return ((uintptr_t)p % n) == 0; };
   if (a.N % BN || a.out_batch_stride % 4 || a.resid_row_mod) return false;
   if (a.out_f32 && (a.ldo_f32 % 4 || !al(a.out_f32, 16))) return false;
@@ -587,7 +597,7 @@ static bool gemm_all_tiles_lean(const fdm_gemm_args& a) {
     const int kcol_lo = a.out_kp ? a.kp_col0 : a.N, kcol_hi = a.out_kp ? (a.out_vp ? a.vp_col0 : a.N) : a.N;
     if (a.kv_hd % 16) return false;
     if (a.out_kp && (kcol_lo % BN || kcol_hi % BN)) return false;
-    if (a.out_vp && (a.vp_col0 % BN || a.kv_L % (16 / (int)sizeof(KV)))) return false;
+    if (a.out_vp && a.vp_col0 % BN) return false;
     if (!a.out_kp && a.out_vp) return false;          // (V-only projections: the general kernel)
   }
   return true;
