@@ -7,8 +7,8 @@ export FDM_TUNE=0
 FDM_TILE_OVERRIDE="qkv=3" bash tools/pmc_collect.sh cfg2_bf16 --dtype bf16 2>&1 | tail -3
 FDM_TILE_OVERRIDE="qkv=3,ffn1=8" bash tools/pmc_collect.sh cfg2_f16x3 --dtype f16x3 2>&1 | tail -3
 FDM_TILE_OVERRIDE="" bash tools/pmc_collect.sh cfg2_f32 --dtype f32 2>&1 | tail -3
-FDM_TILE_OVERRIDE="enc=9,qkv=7,out=9,ffn1=8,ffn2=2,dec=9" bash tools/pmc_collect.sh cfg3_bf16 --dtype bf16 --config cfg3 2>&1 | tail -3
-FDM_TILE_OVERRIDE="enc=6,qkv=7,out=2,ffn1=7,ffn2=2,dec=2" bash tools/pmc_collect.sh cfg5_bf16 --dtype bf16 --config cfg5 2>&1 | tail -3
+FDM_TILE_OVERRIDE="enc=9,qkv=7,out=9,ffn1=6,ffn2=2,dec=9" bash tools/pmc_collect.sh cfg3_bf16 --dtype bf16 --config cfg3 2>&1 | tail -3
+FDM_TILE_OVERRIDE="enc=6,qkv=7,out=2,ffn1=3,ffn2=2,dec=2" bash tools/pmc_collect.sh cfg5_bf16 --dtype bf16 --config cfg5 2>&1 | tail -3
 unset FDM_TUNE FDM_TILE_OVERRIDE
 cd /tmp; export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/stats_default
