@@ -14,6 +14,10 @@
 //    lane ends up with 4 consecutive output columns n of one row m: the epilogue then reads
 //    bias/residual and writes outputs with 16-byte (fp32) / 8-byte (16-bit) vector accesses.
 //  * Epilogue is fused: bias, activation, residual add, dual-dtype stores, transposed "V^T" scatter.
+//  * One kernel template, several instantiations per tile: what a launch is timed by on this path is its fixed cost (boundary,
+//    cold kernel arguments, cold first tile, cold instruction fetch -- tools/gemm_timeline.py), so kernels are specialised
+//    by what the launch can need (SPEC: lean / packed K,V / LayerNorm fold; HEAVY: transcendental activations; SCHED: the
+//    fused scheduler update) and the general edge-handling kernel serves only the shapes that need it.
 #pragma once
 #include <cstdlib>
 #include <cstring>
@@ -67,7 +71,8 @@ __device__ __forceinline__ void gemm_load_rowstats(const fdm_gemm_args& p, int m
 // gemm_epi_preload BEFORE the k loop, so the epilogue is compute + stores only.  Left inside the epilogue these loads
 // sit behind the stores of earlier fragments (the output pointers may alias the inputs as far as the compiler knows),
 // one exposed load latency per (mi, ni) fragment: measured 11 us of fixed cost on a 96x128 tile, ~1 us on 64x64.
-// Issued first, they are older than every ring load, so the k loop's counted vmcnt waits cover them too.
+// They are requested right after the first ring tiles (older than every later tile), so the k loop's counted vmcnt waits
+// cover them too.
 template <int MI, int NI> struct EpiPre { f32x4 csv[NI], bv[NI], gmv[NI], btv[NI], rv[MI][NI]; SchedCoef sc; };
 
 template <typename T, int BM, int BN, int WM, int WN, bool SCHED = false>
