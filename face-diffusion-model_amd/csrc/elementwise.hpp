@@ -29,7 +29,12 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
   const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 v = *(const f32x4*)(p.x + (size_t)row * d + col);
   const bool has_e = p.add_mat || p.add_tab;
-  const f32x4 em = p.add_mat ? *(const f32x4*)(p.add_mat + (size_t)row * d + col) : zero;
+  int arow = row;                      // (uniform: scalar arithmetic) conditions of a clip share the clip's addend rows
+  if (p.add_mat_group > 0) {
+    const int m = p.add_mat_wrap > 0 ? row % p.add_mat_wrap : row;
+    arow = (m / p.add_mat_group) * p.add_mat_L + m % p.add_mat_L;
+  }
+  const f32x4 em = p.add_mat ? *(const f32x4*)(p.add_mat + (size_t)arow * d + col) : zero;
   const f32x4 g1 = *(const f32x4*)(p.gamma + col), b1 = *(const f32x4*)(p.beta + col);
   const float *gp2 = two ? p.gamma2 : p.gamma, *bp2 = two ? p.beta2 : p.beta;      // (a select of pointers, not of loaded data)
   const f32x4 g2 = *(const f32x4*)(gp2 + col), b2 = *(const f32x4*)(bp2 + col);

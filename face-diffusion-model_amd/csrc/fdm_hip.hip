@@ -174,6 +174,9 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
   if (!a->y_f32 && !a->y_t) return fail(FDM_ERR_ARG, "layernorm: no output");
   if (a->dtype < FDM_F32 || a->dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "layernorm: bad dtype %d", a->dtype);
   if (a->y_t && a->dtype >= FDM_F16X3 && (a->y_t_lo_off <= 0 || a->y_t_lo_off % 4)) return fail(FDM_ERR_ARG, "layernorm: split y_t needs y_t_lo_off");
+  if (a->add_mat_group < 0 || a->add_mat_wrap < 0 ||
+      (a->add_mat_group > 0 && (a->add_mat_L <= 0 || a->add_mat_group % a->add_mat_L || (a->add_mat_wrap > 0 && a->add_mat_wrap % a->add_mat_group))))
+    return fail(FDM_ERR_SHAPE, "layernorm: shared add_mat needs add_mat_L | add_mat_group | add_mat_wrap (got %d, %d, %d)", a->add_mat_L, a->add_mat_group, a->add_mat_wrap);
   fdm_ln_args c = *a;
   return submit([c](hipStream_t s) {
     switch (c.dtype) {

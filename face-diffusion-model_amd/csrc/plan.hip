@@ -192,9 +192,9 @@ struct Wt { float* p = nullptr; long long n = 0; };
 struct fdm_plan {
   fdm_model_desc m{};
   int dtype = FDM_F32, hd = 0;
-  std::vector<void*> allocs, ws_allocs;
+  std::vector<void*> allocs, ws_allocs, commit_allocs;     // plan lifetime | per capacity | per commit (freed when weights change)
   std::map<std::string, Wt> w;               // fp32 weights / buffers by reference state-dict name (plan-owned copies)
-  bool committed = false;
+  bool committed = false, in_commit = false;
   // ---- per model
   std::map<std::string, Mat> wt;             // operand-kind copies of the step's matrices
   float* tau = nullptr;
@@ -206,7 +206,8 @@ struct fdm_plan {
   float *c1 = nullptr, *c2 = nullptr, *sigma = nullptr, *sra = nullptr, *srm1 = nullptr;
   // ---- per shape (capacity cap*, current B, L, ...)
   int capB = 0, capL = 0, capRep = 0;
-  int B = 0, L = 0, M = 0, rep = 1, R = 0, Lpad = 0, cfg = 0;
+  int B = 0, L = 0, M = 0, rep = 1, R = 0, Lpad = 0, cfg = 0;     // B = row blocks ("virtual clips") = audio clips x S
+  int S = 1;                                 // conditions per audio clip sharing the clip's AF / C1_l tables (fdm_audio_prepare_conds)
   bool prepared = false;
   float *h = nullptr, *h2 = nullptr, *x1 = nullptr, *x0 = nullptr, *x = nullptr, *x2 = nullptr, *stats = nullptr;
   Mat xt, ht, h2t, x2t, ctx, u;
@@ -223,12 +224,14 @@ struct fdm_plan {
   std::map<int, std::vector<int>> ddim_t;
   // ---- programs and tiles
   std::map<std::string, fdm_prog*> progs;
-  std::vector<std::string> prog_order;
+  std::vector<std::string> prog_order;       // least recently used first
+  std::vector<std::string> pinned;           // programs handed out during the current API call: never evicted by it
   std::map<std::string, int> tiles;
   std::map<std::string, std::map<std::string, int>> tile_cache;     // by shape key
   std::map<std::string, long long> steps_seen;
   std::map<std::string, std::vector<fdm_gemm_args>>* tune_rec = nullptr;
   int tune_enabled = 1;
+  int tune_lazy = 0;                         // 1: fdm_sample_graph may tune in-call once a shape has run 2000 steps (opt-in)
   long long last_graph_launches = 0, launches_per_step = 0;
 };
 
@@ -241,7 +244,7 @@ int dalloc(fdm_plan* P, void** out, size_t bytes, bool ws, bool zero = true) {
   void* p = nullptr;
   HIPCK(hipMalloc(&p, bytes ? bytes : 16));
   if (zero) HIPCK(hipMemset(p, 0, bytes ? bytes : 16));
-  (ws ? P->ws_allocs : P->allocs).push_back(p);
+  (ws ? P->ws_allocs : (P->in_commit ? P->commit_allocs : P->allocs)).push_back(p);     // commit-time tables are freed when a weight changes
   *out = p;
   return FDM_OK;
 }
@@ -260,7 +263,7 @@ Mat mat_rows(const fdm_plan* P, const Mat& m, size_t row0, size_t cols) {
 
 std::string shape_key(const fdm_plan* P) {
   char b[64];
-  snprintf(b, sizeof(b), "%d,%d,%d,%d", P->R, P->M, P->L, P->rep);
+  snprintf(b, sizeof(b), "%d,%d,%d,%d,%d", P->R, P->M, P->L, P->rep, P->S);
   return b;
 }
 
@@ -272,6 +275,7 @@ int drop_programs(fdm_plan* P, void* stream) {
   for (auto& kv : P->progs) fdm_prog_destroy(kv.second);
   P->progs.clear();
   P->prog_order.clear();
+  P->pinned.clear();
   return FDM_OK;
 }
 
@@ -325,8 +329,7 @@ std::string lname(int l, const char* suffix) {
 // ---------------------------------------------------------------------------------------------------------------------
 // commit: per-model tables
 // ---------------------------------------------------------------------------------------------------------------------
-int commit(fdm_plan* P, void* stream) {
-  if (P->committed) return FDM_OK;
+int commit_impl(fdm_plan* P, void* stream) {
   const fdm_model_desc& m = P->m;
   const int d = m.d;
   hipStream_t s = (hipStream_t)stream;
@@ -460,6 +463,31 @@ int commit(fdm_plan* P, void* stream) {
   return FDM_OK;
 }
 
+// Everything commit allocates (operand-kind weight copies, tau / TT tables, folds, schedule and PE tables) is derived from the
+// weights: released when a weight changes under it (fdm_plan_set_weights) and rebuilt by the next commit.
+int release_commit(fdm_plan* P, void* stream) {
+  FCK(drop_programs(P, stream));           // recorded programs point into the tables
+  if (!P->commit_allocs.empty()) {
+    if (stream) HIPCK(hipStreamSynchronize((hipStream_t)stream)); else HIPCK(hipDeviceSynchronize());
+    for (void* p : P->commit_allocs) (void)hipFree(p);
+    P->commit_allocs.clear();
+  }
+  P->committed = false; P->prepared = false;
+  P->wt.clear(); P->fold.clear(); P->TT.clear();
+  P->tau = nullptr; P->slopes = P->pe = nullptr;
+  P->c1 = P->c2 = P->sigma = P->sra = P->srm1 = nullptr;
+  return FDM_OK;
+}
+
+int commit(fdm_plan* P, void* stream) {
+  if (P->committed) return FDM_OK;
+  if (!P->commit_allocs.empty()) FCK(release_commit(P, stream));      // a commit that failed half way
+  P->in_commit = true;
+  const int rc = commit_impl(P, stream);
+  P->in_commit = false;
+  return rc;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // workspaces
 // ---------------------------------------------------------------------------------------------------------------------
@@ -585,6 +613,7 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
     fdm_ln_args ln;
     memset(&ln, 0, sizeof(ln));
     ln.x = P->x1; ln.M = R; ln.d = d; ln.add_mat = P->C1[l]; ln.add_tab = P->TT[l]; ln.tab_step = tcur; ln.eps = eps;
+    if (P->S > 1) { ln.add_mat_L = L; ln.add_mat_group = P->S * L; ln.add_mat_wrap = M; }     // C1_l holds one block per audio clip
     FCK(need(P, lname(l, "norm1.weight"), d, &ln.gamma)); FCK(need(P, lname(l, "norm1.bias"), d, &ln.beta));
     FCK(need(P, lname(l, "norm2.weight"), d, &ln.gamma2)); FCK(need(P, lname(l, "norm2.bias"), d, &ln.beta2));
     ln.y_f32 = P->h2; ln.dtype = P->dtype;
@@ -641,13 +670,26 @@ int get_program(fdm_plan* P, const ProgSpec& sp, void* stream, fdm_prog** out) {
   char key[256];
   snprintf(key, sizeof(key), "%d|%p|%a|%p|%d", sp.kind, (const void*)sp.noise, (double)sp.cfg_scale, (const void*)sp.san, sp.reps);
   auto it = P->progs.find(key);
-  if (it != P->progs.end()) { *out = it->second; return FDM_OK; }
-  if (P->progs.size() >= 8) {          // programs are keyed by the pointers they captured (e.g. injected noise): cap the cache
-    HIPCK(hipStreamSynchronize((hipStream_t)stream));
-    const std::string victim = P->prog_order.front();
-    P->prog_order.erase(P->prog_order.begin());
-    fdm_prog_destroy(P->progs[victim]);
-    P->progs.erase(victim);
+  if (it != P->progs.end()) {            // hit: most recently used goes to the back, and the caller's handle stays valid for this call
+    auto pos = std::find(P->prog_order.begin(), P->prog_order.end(), std::string(key));
+    if (pos != P->prog_order.end()) { P->prog_order.erase(pos); P->prog_order.push_back(key); }
+    P->pinned.push_back(key);
+    *out = it->second;
+    return FDM_OK;
+  }
+  if (P->progs.size() >= 8) {
+    // programs are keyed by the pointers they captured (e.g. injected noise): cap the cache.  Victim = least recently used
+    // program that was NOT handed out earlier in this API call (fdm_sample_graph holds two: the 1-step and the K-step one).
+    auto victim = P->prog_order.end();
+    for (auto v = P->prog_order.begin(); v != P->prog_order.end(); ++v)
+      if (std::find(P->pinned.begin(), P->pinned.end(), *v) == P->pinned.end()) { victim = v; break; }
+    if (victim != P->prog_order.end()) {
+      HIPCK(hipStreamSynchronize((hipStream_t)stream));
+      const std::string vk = *victim;
+      P->prog_order.erase(victim);
+      fdm_prog_destroy(P->progs[vk]);
+      P->progs.erase(vk);
+    }
   }
   const int d = P->m.d, M = P->M;
   const long long n = (long long)M * d;
@@ -689,6 +731,7 @@ int get_program(fdm_plan* P, const ProgSpec& sp, void* stream, fdm_prog** out) {
   if (sp.reps == 1) P->launches_per_step = fdm_prog_num_ops(prog);
   P->progs[key] = prog;
   P->prog_order.push_back(key);
+  P->pinned.push_back(key);
   *out = prog;
   return FDM_OK;
 }
@@ -696,7 +739,9 @@ int get_program(fdm_plan* P, const ProgSpec& sp, void* stream, fdm_prog** out) {
 int set_steps(fdm_plan* P, const int* ts, int n, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (n > P->tseq_cap) {
-    FCK(drop_programs(P, stream));
+    FCK(drop_programs(P, stream));          // (drains the stream: nothing reads the old list any more)
+    auto old = std::find(P->allocs.begin(), P->allocs.end(), (void*)P->tseq);
+    if (old != P->allocs.end()) { P->allocs.erase(old); (void)hipFree(P->tseq); }
     P->tseq_cap = n;
     FCK(dalloc_t(P, &P->tseq, (size_t)n, false));
   }
@@ -748,7 +793,7 @@ int time_prog(fdm_prog* prog, int warm, int reps, hipStream_t s, float* ms) {
   return rc;
 }
 
-void apply_tile_override(fdm_plan* P) {      // FDM_TILE_OVERRIDE="qkv_ln=5,ffn1=3": force call sites (experiments, pinned profiles)
+void apply_tile_override(std::map<std::string, int>& tiles) {      // FDM_TILE_OVERRIDE="qkv_ln=5,ffn1=3": force call sites (experiments, pinned profiles)
   const char* ov = getenv("FDM_TILE_OVERRIDE");
   if (!ov) return;
   const std::string sov(ov);
@@ -756,35 +801,33 @@ void apply_tile_override(fdm_plan* P) {      // FDM_TILE_OVERRIDE="qkv_ln=5,ffn1
   while (pos < sov.size()) {
     const size_t comma = sov.find(',', pos), eq = sov.find('=', pos);
     const size_t end = comma == std::string::npos ? sov.size() : comma;
-    if (eq != std::string::npos && eq < end) P->tiles[sov.substr(pos, eq - pos)] = atoi(sov.substr(eq + 1, end - eq - 1).c_str());
+    if (eq != std::string::npos && eq < end) tiles[sov.substr(pos, eq - pos)] = atoi(sov.substr(eq + 1, end - eq - 1).c_str());
     pos = end + 1;
   }
 }
 
-int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
-  // Time the candidate output tiles of every GEMM call site of the step at this plan's shapes and keep the fastest.  Each
-  // candidate runs the call site's per-layer instances (distinct weights, so they come from beyond L2 as they do inside the
-  // step) as a replayed graph; cached per shape, and lazily only for shapes the plan keeps being used at (after 2000 steps;
-  // n_steps < 0 forces).  Every tile accumulates k in the same order, so the choice changes speed only, never results.
+int tune_tiles_impl(fdm_plan* P, void* stream);
+
+// Time the candidate output tiles of every GEMM call site of the step at this plan's shapes and keep the fastest.  Cached per
+// shape.  Tuning is PLAN-TIME work (it records, instantiates and times dozens of graphs with stream drains in between):
+//   force != 0          fdm_plan_tune
+//   force == 0          fdm_audio_prepare, for a shape that earlier sampling calls have run >= 2000 steps at (serving)
+// fdm_sample_graph itself only counts steps per shape, unless the caller opted in to in-call tuning
+// (fdm_plan_set(p, "tune_lazy", 1)).  Every tile accumulates k in the same order, so the choice changes speed only, never results.
+int tune_tiles(fdm_plan* P, int force, void* stream) {
   const std::string key = shape_key(P);
   const char* env = getenv("FDM_TUNE");
   if (P->tile_cache.count(key)) return FDM_OK;
-  if (!P->tune_enabled || (env && !strcmp(env, "0"))) {
-    // tuning off: the library heuristic, or the pinned set of FDM_TILE_OVERRIDE ("qkv=8,ffn1=2": reproducible profiles)
-    if (getenv("FDM_TILE_OVERRIDE") && n_steps < 0) {
-      FCK(drop_programs(P, stream));
-      P->tiles.clear();
-      apply_tile_override(P);
-      P->tile_cache[key] = P->tiles;
-    }
-    return FDM_OK;
-  }
-  if (n_steps >= 0) {
-    long long& seen = P->steps_seen[key];
-    const long long before = seen;
-    seen += n_steps;
-    if (before < 2000) return FDM_OK;
-  }
+  if (!P->tune_enabled || (env && !strcmp(env, "0"))) return FDM_OK;       // heuristic tiles, or the pinned set of FDM_TILE_OVERRIDE
+  if (!force && P->steps_seen[key] < 2000) return FDM_OK;
+  const std::map<std::string, int> before = P->tiles;
+  const int rc = tune_tiles_impl(P, stream);
+  if (rc != FDM_OK) { P->tiles = before; (void)drop_programs(P, stream); }   // never leave a trial set behind
+  return rc;
+}
+
+int tune_tiles_impl(fdm_plan* P, void* stream) {
+  const std::string key = shape_key(P);
   hipStream_t s = (hipStream_t)stream;
   FCK(drop_programs(P, stream));
   P->tiles.clear();
@@ -913,7 +956,7 @@ int tune_tiles(fdm_plan* P, long long n_steps, void* stream) {
     }
   }
   P->tiles = keep;
-  apply_tile_override(P);
+  apply_tile_override(P->tiles);
   P->tile_cache[key] = P->tiles;
   return FDM_OK;
 }
@@ -956,6 +999,7 @@ int fdm_plan_destroy(fdm_plan* P) {
   (void)hipDeviceSynchronize();
   for (auto& kv : P->progs) fdm_prog_destroy(kv.second);
   for (void* p : P->ws_allocs) (void)hipFree(p);
+  for (void* p : P->commit_allocs) (void)hipFree(p);
   for (void* p : P->allocs) (void)hipFree(p);
   delete P;
   return FDM_OK;
@@ -963,16 +1007,23 @@ int fdm_plan_destroy(fdm_plan* P) {
 
 int fdm_plan_set_weights(fdm_plan* P, const char* name, const float* ptr, long long n, void* stream) {
   if (!P || !name || !ptr || n <= 0) return fail(FDM_ERR_ARG, "plan_set_weights: bad argument");
+  // a weight changed under the derived tables (and under recorded programs that point at the fp32 masters): release them,
+  // the next prepare / commit rebuilds
+  if (P->committed || !P->commit_allocs.empty()) FCK(release_commit(P, stream));
   Wt& w = P->w[name];
   if (w.n != n) {
+    if (w.p) {                               // size change: the old tensor goes (nothing references it after release_commit)
+      FCK(drop_programs(P, stream));
+      HIPCK(hipStreamSynchronize((hipStream_t)stream));
+      auto it = std::find(P->allocs.begin(), P->allocs.end(), (void*)w.p);
+      if (it != P->allocs.end()) P->allocs.erase(it);
+      (void)hipFree(w.p);
+      w.p = nullptr;
+    }
     w.n = n;
     FCK(dalloc_t(P, &w.p, (size_t)n, false));
   }
   HIPCK(hipMemcpyAsync(w.p, ptr, (size_t)n * 4, hipMemcpyDefault, (hipStream_t)stream));
-  if (P->committed) {      // a weight changed under the derived tables: rebuild them at the next prepare
-    P->committed = false; P->prepared = false;
-    P->wt.clear(); P->fold.clear();
-  }
   return FDM_OK;
 }
 
@@ -982,20 +1033,26 @@ int fdm_plan_commit(fdm_plan* P, void* stream) {
 }
 
 int fdm_audio_prepare(fdm_plan* P, const float* hub, int B, int N, int fw, const float* style, const float* emo, int L, int cfg, void* stream) {
+  return fdm_audio_prepare_conds(P, hub, B, N, fw, 1, style, emo, L, cfg, stream);
+}
+
+int fdm_audio_prepare_conds(fdm_plan* P, const float* hub, int B0, int N, int fw, int S, const float* style, const float* emo, int L, int cfg, void* stream) {
   if (!P || !hub || !style) return fail(FDM_ERR_ARG, "audio_prepare: null argument");
   const fdm_model_desc& m = P->m;
-  if (B < 1 || N < 1 || fw < 1) return fail(FDM_ERR_SHAPE, "audio_prepare: bad feature shape [%d, %d, %d]", B, N, fw);
+  if (B0 < 1 || N < 1 || fw < 1) return fail(FDM_ERR_SHAPE, "audio_prepare: bad feature shape [%d, %d, %d]", B0, N, fw);
+  if (S < 1) return fail(FDM_ERR_SHAPE, "audio_prepare: S=%d conditions per clip", S);
   if (m.pair * fw != m.audio_in) return fail(FDM_ERR_SHAPE, "audio_prepare: audio feature width %d x pair %d != audio_extract input %d", fw, m.pair, m.audio_in);
   if (L < 1 || L > N / m.pair || L > m.max_len) return fail(FDM_ERR_SHAPE, "audio_prepare: latent frames L=%d outside [1, min(%d, %d)] (models/fdm_vocaset.py:44,64-66)", L, N / m.pair, m.max_len);
   if (m.n_emo && !emo) return fail(FDM_ERR_ARG, "audio_prepare: this model needs an emotion one-hot");
+  const int B = B0 * S;                      // row blocks of the step program
   FCK(commit(P, stream));
   FCK(reserve(P, B, L, cfg));
   // recorded programs hold the workspace pointers and the shape, not the clip tables' contents: a new batch of the same
   // shape (serving) keeps them and their instantiated graphs
-  if (!(P->prepared && P->B == B && P->L == L && P->cfg == (cfg ? 1 : 0))) FCK(drop_programs(P, stream));
+  if (!(P->prepared && P->B == B && P->S == S && P->L == L && P->cfg == (cfg ? 1 : 0))) FCK(drop_programs(P, stream));
   hipStream_t s = (hipStream_t)stream;
-  const int d = m.d, M = B * L, rep = cfg ? 2 : 1;
-  P->B = B; P->L = L; P->M = M; P->rep = rep; P->R = M * rep; P->cfg = cfg ? 1 : 0; P->Lpad = (L + 31) / 32 * 32;
+  const int d = m.d, M0 = B0 * L, M = B * L, rep = cfg ? 2 : 1;
+  P->B = B; P->S = S; P->L = L; P->M = M; P->rep = rep; P->R = M * rep; P->cfg = cfg ? 1 : 0; P->Lpad = (L + 31) / 32 * 32;
   // pad keys of the packed K / V buffers must be finite: the layout depends on (L, Lpad), so clear them per shape
   HIPCK(hipMemsetAsync(P->kp, 0, P->kv_bytes, s));
   HIPCK(hipMemsetAsync(P->vp, 0, P->kv_bytes, s));
@@ -1004,25 +1061,27 @@ int fdm_audio_prepare(fdm_plan* P, const float* hub, int B, int N, int fw, const
   FCK(need(P, "audio_extract.2.weight", (long long)d * d, &w2)); FCK(need(P, "audio_extract.2.bias", d, &b2));
   // audio rows: `pair` consecutive encoder frames per latent frame (models/fdm_vqvae_mead.py:73), cropped to L (:64-66);
   // the rows of a clip are contiguous in hub, so each clip's GEMM reads them in place (fp32: once per clip, parity)
-  for (int b = 0; b < B; ++b) {
+  for (int b = 0; b < B0; ++b) {
     fdm_gemm_args g = gemm_f32(hub + (size_t)b * N * fw, w0, L, d, m.audio_in);
     g.bias = b0; g.act = FDM_ACT_MISH; g.out_f32 = P->t1 + (size_t)b * L * d;
     FCK(fdm_op_gemm(&g, stream));
   }
-  fdm_gemm_args g = gemm_f32(P->t1, w2, M, d, d);
+  fdm_gemm_args g = gemm_f32(P->t1, w2, M0, d, d);
   g.bias = b2; g.out_f32 = P->AF;
   FCK(fdm_op_gemm(&g, stream));
-  // folded cross-attention tables C1_l = Wo_l (Wv_l AF + bv_l) + bo_l, layout [rep][M, d]
+  // folded cross-attention tables C1_l = Wo_l (Wv_l AF + bv_l) + bo_l.  S = 1: layout [rep][M, d] (the uncond half is a copy);
+  // S > 1: ONE block of [B0 * L, d] per layer, every condition (and both CFG halves) of a clip reads its clip's rows through
+  // the LayerNorm kernel's row map (fdm_ln_args.add_mat_group) -- no table work per condition
   for (int l = 0; l < m.n_layers; ++l) {
-    g = gemm_f32(P->AF, P->Wv[l], M, d, d);
+    g = gemm_f32(P->AF, P->Wv[l], M0, d, d);
     g.bias = P->bv[l]; g.out_f32 = P->t1;
     FCK(fdm_op_gemm(&g, stream));
-    g = gemm_f32(P->t1, P->Wo[l], M, d, d);
+    g = gemm_f32(P->t1, P->Wo[l], M0, d, d);
     g.bias = P->bo[l]; g.out_f32 = P->C1[l];
     FCK(fdm_op_gemm(&g, stream));
-    if (rep == 2) HIPCK(hipMemcpyAsync(P->C1[l] + (size_t)M * d, P->C1[l], (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
+    if (rep == 2 && S == 1) HIPCK(hipMemcpyAsync(P->C1[l] + (size_t)M * d, P->C1[l], (size_t)M * d * 4, hipMemcpyDeviceToDevice, s));
   }
-  // conditioning addend E0 = PE[l] + style[b] (+ emotion[b]) (:75-84)
+  // conditioning addend E0 = PE[l] + style[b] (+ emotion[b]) (:75-84), one row block per (clip, condition)
   const float *sw = nullptr, *sbias = nullptr;
   FCK(need(P, "style_embedd.weight", (long long)d * m.n_style, &sw)); FCK(need(P, "style_embedd.bias", d, &sbias));
   FCK(fdm_op_small_linear(style, sw, sbias, P->sty, B, m.n_style, d, m.style_mish ? FDM_ACT_MISH : FDM_ACT_NONE, stream));
@@ -1039,12 +1098,16 @@ int fdm_audio_prepare(fdm_plan* P, const float* hub, int B, int N, int fw, const
   }
   P->prepared = true;
   auto it = P->tile_cache.find(shape_key(P));
-  P->tiles = it == P->tile_cache.end() ? std::map<std::string, int>() : it->second;
-  return FDM_OK;
+  std::map<std::string, int> want;
+  if (it != P->tile_cache.end()) want = it->second;
+  else apply_tile_override(want);          // FDM_TILE_OVERRIDE pins tiles with or without the tuner (heuristic tiles elsewhere)
+  if (want != P->tiles) { FCK(drop_programs(P, stream)); P->tiles = want; }
+  return tune_tiles(P, 0, stream);        // plan-time: only for a shape that has already served >= 2000 steps untuned
 }
 
 int fdm_denoise_step(fdm_plan* P, const float* x_t, int t, float cfg_scale, float* x0_hat, float* x0_uncond, void* stream) {
   FCK(check_ready(P));
+  P->pinned.clear();
   if (!x_t || !x0_hat || t < 0 || t >= 1000) return fail(FDM_ERR_ARG, "denoise_step: bad argument (t = %d)", t);
   FCK(load_x(P, x_t, stream));
   FCK(set_steps(P, &t, 1, stream));
@@ -1060,6 +1123,7 @@ int fdm_denoise_step(fdm_plan* P, const float* x_t, int t, float cfg_scale, floa
 
 int fdm_sample_graph(fdm_plan* P, const fdm_sample_args* a, void* stream) {
   FCK(check_ready(P));
+  P->pinned.clear();
   if (!a || !a->x_T || !a->out) return fail(FDM_ERR_ARG, "sample_graph: null argument");
   hipStream_t s = (hipStream_t)stream;
   std::vector<int> ts;
@@ -1101,7 +1165,8 @@ int fdm_sample_graph(fdm_plan* P, const fdm_sample_args* a, void* stream) {
     if (a->out != a->x_T) HIPCK(hipMemcpyAsync(a->out, a->x_T, nb, hipMemcpyDeviceToDevice, s));
     return FDM_OK;
   }
-  FCK(tune_tiles(P, n_steps, stream));
+  if (P->tune_lazy) FCK(tune_tiles(P, 0, stream));
+  P->steps_seen[shape_key(P)] += n_steps;
   FCK(load_x(P, a->x_T, stream));
   FCK(set_steps(P, ts.data(), n_steps, stream));
   fdm_prog* p1 = nullptr;
@@ -1138,7 +1203,7 @@ int fdm_sample_graph(fdm_plan* P, const fdm_sample_args* a, void* stream) {
 
 int fdm_plan_tune(fdm_plan* P, void* stream) {
   FCK(check_ready(P));
-  return tune_tiles(P, -1, stream);
+  return tune_tiles(P, 1, stream);
 }
 
 int fdm_plan_get(fdm_plan* P, const char* key, long long* out) {
@@ -1158,6 +1223,7 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
   if (!P || !key) return fail(FDM_ERR_ARG, "plan_set: null argument");
   const std::string k(key);
   if (k == "tune") { P->tune_enabled = value != 0; return FDM_OK; }
+  if (k == "tune_lazy") { P->tune_lazy = value != 0; return FDM_OK; }
   if (k == "untune") {      // forget the tuned tiles of every shape (tests)
     P->tile_cache.clear(); P->steps_seen.clear(); P->tiles.clear();
     return drop_programs(P, nullptr);

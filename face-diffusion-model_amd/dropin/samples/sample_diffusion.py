@@ -24,15 +24,24 @@ def synthetic_loader(p, clips, seconds, seed=0):
 
 
 @torch.no_grad()
-def sample_step(loader, dev, diffusion, autoencoder, save_folder, p, ddim_steps, emotion=4, all_styles=False):
+def sample_step(loader, dev, diffusion, autoencoder, save_folder, p, ddim_steps, emotion=4, all_styles=False, batched=True):
+    """The reference loops the style one-hots of a clip through one B = 1 sampling call each, with the same audio
+    (samples/sample_diffusion_vocaset.py:71-83).  Here all styles of a clip are ONE call (condition-batched step program:
+    the audio encoder and audio tables run once per clip); batched=False keeps the sequential loop (same files, bit-identical
+    DDIM results)."""
     os.makedirs(save_folder, exist_ok=True)
     for audio, template, one_hot_all, file_name in loader:
-        styles = range(one_hot_all.shape[1]) if all_styles else [0]
-        for it in styles:                                               # samples/sample_diffusion_vocaset.py:71
-            id_one_hot = one_hot_all[:, it, :]
-            emo = torch.eye(p.n_emo)[emotion:emotion + 1] if p.n_emo else None
-            out, _ = pipeline.animate(diffusion, autoencoder, audio, template, id_one_hot, emo,
-                                      ddim_steps=None if p.n_emo else ddim_steps, device=dev)
+        styles = list(range(one_hot_all.shape[1])) if all_styles else [0]
+        emo = torch.eye(p.n_emo)[emotion:emotion + 1] if p.n_emo else None
+        steps = None if p.n_emo else ddim_steps
+        if batched and len(styles) > 1:
+            ids = one_hot_all[0, styles, :]                              # [S, n_style]: one call for the whole style loop
+            outs, _ = pipeline.animate(diffusion, autoencoder, audio, template, ids, emo, ddim_steps=steps, device=dev)
+            outs = [outs[i:i + 1] for i in range(len(styles))]
+        else:
+            outs = [pipeline.animate(diffusion, autoencoder, audio, template, one_hot_all[:, it, :], emo, ddim_steps=steps,
+                                     device=dev)[0] for it in styles]    # samples/sample_diffusion_vocaset.py:71
+        for it, out in zip(styles, outs):
             dst = os.path.join(save_folder, f"{file_name[:-4]}_condition_{it}")
             np.save(dst, out.detach().cpu().numpy())
             print(f"saved {dst}.npy {tuple(out.shape)}")
@@ -48,7 +57,10 @@ if __name__ == "__main__":
     ap.add_argument("--out", default="result")
     ap.add_argument("--stage1_model_path", default="")
     ap.add_argument("--stage2_model_path", default="")
+    ap.add_argument("--all_styles", action="store_true", help="every style one-hot of each clip (the reference's loop), as one batched call")
+    ap.add_argument("--sequential", action="store_true", help="with --all_styles: one B = 1 call per style, as the reference does")
     a = ap.parse_args()
     p = presets.get(a.dataset)
     diffusion, ae = pipeline.build_models(a.dataset, None, a.device, a.stage1_model_path, a.stage2_model_path)
-    sample_step(synthetic_loader(p, a.clips, a.seconds), a.device, diffusion, ae, a.out, p, a.ddim_steps)
+    sample_step(synthetic_loader(p, a.clips, a.seconds), a.device, diffusion, ae, a.out, p, a.ddim_steps,
+                all_styles=a.all_styles, batched=not a.sequential)

@@ -65,7 +65,8 @@ class AttnArgs(C.Structure):
 class LnArgs(C.Structure):
     _fields_ = [("x", vp), ("M", ci), ("d", ci), ("add_mat", vp), ("add_tab", vp),
                 ("tab_index", vp), ("tab_step", vp), ("gamma", vp), ("beta", vp), ("eps", cf),
-                ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci), ("gamma2", vp), ("beta2", vp), ("y_t_lo_off", ll)]
+                ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci), ("gamma2", vp), ("beta2", vp), ("y_t_lo_off", ll),
+                ("add_mat_L", ci), ("add_mat_group", ci), ("add_mat_wrap", ci)]
 
 
 # every symbol include/fdm_hip.h declares: name -> (restype, argtypes)
@@ -110,6 +111,7 @@ SYMBOLS = {
     "fdm_plan_set_weights": (ci, [vp, C.c_char_p, vp, ll, vp]),
     "fdm_plan_commit": (ci, [vp, vp]),
     "fdm_audio_prepare": (ci, [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp]),
+    "fdm_audio_prepare_conds": (ci, [vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp]),
     "fdm_denoise_step": (ci, [vp, vp, ci, cf, vp, vp, vp]),
     "fdm_sample_graph": (ci, [vp, C.POINTER(SampleArgs), vp]),
     "fdm_plan_tune": (ci, [vp, vp]),

@@ -47,6 +47,7 @@ class DenoiserPlan:
             raise FdmError("DenoiserPlan runs on the HIP path only (no CPU fallback)")
         self.h = None
         self.B = self.L = self.M = 0
+        self.S = 1
         self.cfg = False
         self._keep, self._inputs = [], None
         h = C.c_void_p()
@@ -81,30 +82,42 @@ class DenoiserPlan:
             pass
 
     # ------------------------------------------------------------------------------------------
-    def prepare(self, hub, style, emo=None, L=None, cfg=False):
-        """hub [B, N, fw] audio-encoder features; style [B, n_style]; emo [B, n_emo]; L latent frames."""
+    def prepare(self, hub, style, emo=None, L=None, cfg=False, n_conds=1):
+        """hub [B, N, fw] audio-encoder features; style [B, n_style]; emo [B, n_emo]; L latent frames.
+
+        n_conds = S > 1: S conditions per clip in ONE step program (fdm_audio_prepare_conds) -- what the reference's
+        samplers do as S sequential B = 1 calls with the same audio (samples/sample_diffusion_vocaset.py:71-83).  style
+        [B*S, n_style] / emo [B*S, n_emo] in (clip, condition) order; the plan's batch becomes B*S row blocks (x_T, noise,
+        outputs are [B*S, L*G, c]); the audio tables are computed once per clip and shared by its conditions."""
         p, dv = self.p, self.device
         hub = _dev(hub, dv)
         B, N, fw = hub.shape
+        S = int(n_conds)
+        if S < 1:
+            raise FdmError(f"n_conds={S}")
         nfa = N // p.pair
         L = nfa if L is None else min(L, nfa)
         if L < 1 or L > p.max_len:
             raise FdmError(f"latent frames L={L} outside [1, {p.max_len}] (models/fdm_vocaset.py:44)")
         if style.dim() == 1:
-            style = style.unsqueeze(0).expand(B, -1)
+            style = style.unsqueeze(0).expand(B * S, -1)
+        if style.shape[0] != B * S:
+            raise FdmError(f"style has {style.shape[0]} rows, expected clips x conditions = {B * S}")
         style = _dev(style, dv)
         if p.n_emo:
             if emo is None:
                 raise FdmError("this preset needs an emotion one-hot")
             if emo.dim() == 1:
-                emo = emo.unsqueeze(0).expand(B, -1)
+                emo = emo.unsqueeze(0).expand(B * S, -1)
+            if emo.shape[0] != B * S:
+                raise FdmError(f"emotion one-hot has {emo.shape[0]} rows, expected clips x conditions = {B * S}")
             emo = _dev(emo, dv)
         with torch.cuda.device(dv):
-            check(lib().fdm_audio_prepare(self.h, hub.data_ptr(), B, N, fw, style.data_ptr(),
-                                          emo.data_ptr() if p.n_emo else None, L, int(bool(cfg)), _stream()))
+            check(lib().fdm_audio_prepare_conds(self.h, hub.data_ptr(), B, N, fw, S, style.data_ptr(),
+                                                emo.data_ptr() if p.n_emo else None, L, int(bool(cfg)), _stream()))
         # the library reads hub / style / emo asynchronously on this stream: keep them alive until the next prepare
         self._inputs = (hub, style, emo)
-        self.B, self.L, self.M, self.cfg = B, L, B * L, bool(cfg)
+        self.B, self.L, self.M, self.cfg, self.S = B * S, L, B * S * L, bool(cfg), S
         return L
 
     def _check_x(self, x):
@@ -173,8 +186,8 @@ class DenoiserPlan:
 
     # ------------------------------------------------------------------------------------------
     def tune(self):
-        """Tune the GEMM tiles for the prepared shape now (plan-time work; sampling calls otherwise do it lazily, once a
-        shape has run 2000 steps)."""
+        """Tune the GEMM tiles for the prepared shape now (plan-time work; otherwise prepare() does it for a shape that
+        sampling calls have already run 2000 steps at -- never inside a sampling call)."""
         with torch.cuda.device(self.device):
             check(lib().fdm_plan_tune(self.h, _stream()))
 

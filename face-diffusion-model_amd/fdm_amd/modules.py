@@ -258,6 +258,9 @@ class _FDMBase(ParamTree):
         return self._hub
 
     def prepare(self, audio, L, style, emo=None, cfg=False):
+        """Per-batch tables of the plan.  style [B, n] (one condition per clip, the reference's call shape) or [B*S, n] with
+        S > 1: S conditions per clip -- the style loop of samples/sample_diffusion_vocaset.py:71-83 as ONE step program
+        (rows in (clip, condition) order; the audio encoder and the audio tables still run once per clip)."""
         hub = self.audio_features(audio)
         plan = self.plan(hub.device)
         key = (L, bool(cfg), tuple(style.flatten().tolist()), None if emo is None else tuple(emo.flatten().tolist()))
@@ -266,7 +269,14 @@ class _FDMBase(ParamTree):
             B = hub.shape[0]
             st = style.reshape(-1, style.shape[-1])
             em = None if emo is None else emo.reshape(-1, emo.shape[-1])
-            plan.prepare(hub, st if st.shape[0] == B else st[0], em if (em is None or em.shape[0] == B) else em[0], L=L, cfg=cfg)
+            rows = max(st.shape[0], 1 if em is None else em.shape[0], B)
+            if rows % B:
+                raise FdmError(f"{rows} condition rows for {B} clips: expected a multiple (conditions per clip)")
+            S = rows // B
+            if st.shape[0] not in (1, rows) or (em is not None and em.shape[0] not in (1, rows)):
+                raise FdmError("style / emotion one-hots must have one row, or one row per (clip, condition)")
+            plan.prepare(hub, st if st.shape[0] == rows else st[0], em if (em is None or em.shape[0] == rows) else em[0],
+                         L=L, cfg=cfg, n_conds=S)
             self._prep_key = (_TensorKey(hub), key)
         return plan
 
@@ -441,7 +451,7 @@ class GaussianDiffusion(nn.Module):
         if noise is not None:
             x_T, z = noise[0].to(dev), noise[1]
             return plan.sample_ddpm(x_T.float().contiguous(), ts, noise=z, cfg_scale=scale)
-        x_T = torch.randn(shape, device=dev)
+        x_T = torch.randn((plan.B,) + tuple(shape[1:]), device=dev)      # one row block per (clip, condition)
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if seed is None else int(seed)
         return plan.sample_ddpm(x_T, ts, seed=seed, cfg_scale=scale)
 
@@ -451,8 +461,12 @@ class GaussianDiffusion(nn.Module):
 
     @torch.no_grad()
     def ddim_sample(self, audio, latent_motion_shape, id_one_hot, steps=500, *, x_T=None, guidance_scale=None):
+        """id_one_hot [1, n] / [B, n]: the reference's call.  [B*S, n] with S > 1: the S style conditions of every clip in
+        one call (the sampler's style loop, samples/sample_diffusion_vocaset.py:71-83, batched); returns [B*S, L*G, c] in
+        (clip, condition) order, each block bit-identical to the one-condition call with the same x_T block."""
         plan, scale = self._plan(audio, latent_motion_shape, (id_one_hot,), guidance_scale)
-        x_T = torch.randn(latent_motion_shape, device=plan.device) if x_T is None else x_T.to(plan.device)
+        shape = (plan.B,) + tuple(latent_motion_shape[1:])
+        x_T = torch.randn(shape, device=plan.device) if x_T is None else x_T.to(plan.device)
         return plan.sample_ddim(x_T.float().contiguous(), steps, cfg_scale=scale)
 
     def forward(self, x, audio, *cond):

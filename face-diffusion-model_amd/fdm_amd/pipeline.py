@@ -69,7 +69,13 @@ def build_models(preset="vocaset", feature_dim=None, device="cuda:0", stage1=Non
 @torch.no_grad()
 def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emotion_one_hot=None, steps=None,
             ddim_steps=None, seed=0, device="cuda:0"):
-    """audio [B, n] (processor-normalised) -> vertices [B, L, V3].  DDPM full chain by default, DDIM if ddim_steps."""
+    """audio [B, n] (processor-normalised) -> vertices [B, L, V3].  DDPM full chain by default, DDIM if ddim_steps.
+
+    id_one_hot [B*S, n_style] (and emotion_one_hot [B*S, n_emo]) with S > 1 animates every clip under S conditions in ONE
+    sampling call -- the reference sampler's style loop (samples/sample_diffusion_vocaset.py:71-83) batched: the audio
+    encoder and the audio tables run once per clip, the S conditions ride the same step program.  Returns [B*S, L, V3] in
+    (clip, condition) order; every condition of a clip starts from the clip's x_T (what S sequential calls with the same
+    seed do), so the DDIM results are bit-identical to the sequential loop's."""
     model = diffusion.denoise_fn.model if isinstance(diffusion.denoise_fn, ClassifierFreeSampleModel) else diffusion.denoise_fn
     p = model.preset
     audio = torch.as_tensor(audio, dtype=torch.float32, device=device)
@@ -78,26 +84,36 @@ def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emoti
     B = audio.shape[0]
     if id_one_hot is None:
         id_one_hot = torch.eye(p.n_style)[:1].expand(B, -1)
-    id_one_hot = id_one_hot.to(device)
+    id_one_hot = id_one_hot.reshape(-1, id_one_hot.shape[-1]).to(device)
+    rows = max(id_one_hot.shape[0], 1 if emotion_one_hot is None else emotion_one_hot.reshape(-1, emotion_one_hot.shape[-1]).shape[0], B)
+    if rows % B:
+        raise ValueError(f"{rows} condition rows for {B} clips")
+    S = rows // B
     hub = model.audio_features(audio)
     L = min(hub.shape[1] // p.pair, p.max_len)        # samples/sample_diffusion_vocaset.py:76 (no interpolation, a17b)
     shape = (B, L * p.G, p.c)
     if p.n_emo:
         if emotion_one_hot is None:
-            emotion_one_hot = torch.eye(p.n_emo)[4:5].expand(B, -1)
-        emotion_one_hot = emotion_one_hot.to(device)
+            emotion_one_hot = torch.eye(p.n_emo)[4:5].expand(rows, -1)
+        emotion_one_hot = emotion_one_hot.reshape(-1, emotion_one_hot.shape[-1]).to(device)
+        if emotion_one_hot.shape[0] == 1 and rows > 1:
+            emotion_one_hot = emotion_one_hot.expand(rows, -1)
+        if id_one_hot.shape[0] == 1 and rows > 1:
+            id_one_hot = id_one_hot.expand(rows, -1)
         latent = diffusion.sample(audio, shape, emotion_one_hot, id_one_hot, seed=seed)
         quanted, _, _ = autoencoder.quant(latent, emotion_one_hot)
     else:
         if ddim_steps:
             g = torch.Generator(device="cpu").manual_seed(seed)
-            latent = diffusion.ddim_sample(audio, shape, id_one_hot, ddim_steps, x_T=torch.randn(shape, generator=g))
+            x_T = torch.randn(shape, generator=g).repeat_interleave(S, dim=0)
+            latent = diffusion.ddim_sample(audio, shape, id_one_hot, ddim_steps, x_T=x_T)
         else:
             latent = diffusion.sample(audio, shape, id_one_hot, seed=seed)
         quanted, _, _ = autoencoder.quant(latent)
     out = autoencoder.decode(quanted)
     if template is not None:
-        out = out + torch.as_tensor(template, dtype=torch.float32, device=device).reshape(-1, 1, out.shape[-1])
+        tp = torch.as_tensor(template, dtype=torch.float32, device=device).reshape(-1, 1, out.shape[-1])
+        out = out + (tp.repeat_interleave(S, dim=0) if (S > 1 and tp.shape[0] == B and B > 1) else tp)
     return out, latent
 
 

@@ -5,8 +5,18 @@
  * ddim_sample / p_sample, HubertModel.forward, VQAutoEncoder.quant / decode).  Every entry point
  * below names the reference interface (file:line under /root/reference) whose arithmetic it
  * replaces.  All functions take raw device pointers, sizes and a hipStream_t (passed as void*),
- * return 0 on success or a negative error code (message via fdm_last_error()), never throw and
- * never synchronise the device.  Nothing here takes or returns a torch type.
+ * return 0 on success or a negative error code (message via fdm_last_error()) and never throw.
+ * Nothing here takes or returns a torch type.
+ *
+ * Synchronisation contract, per layer:
+ *   fdm_op_*, fdm_prog_run / _replay     enqueue on the given stream and return: they never synchronise
+ *   fdm_prog_instantiate / _destroy      graph capture / release (host work; _destroy expects the stream drained)
+ *   fdm_plan_commit, _reserve, _tune, _set("tile.*"), fdm_plan_set_weights after a commit, fdm_audio_prepare when it
+ *     has to commit, grow the workspaces or tune               PLAN-TIME: allocate and drain the stream
+ *   fdm_sample_graph, fdm_denoise_step   ONE stream drain per call (the timestep list / seed are host memory of the
+ *     caller and are uploaded before the loop), plus graph instantiation the first time a program shape is used and a
+ *     drain when the 8-entry program cache evicts; NOTHING synchronises inside the T-step loop
+ *   fdm_hubert_forward, fdm_vq_*         drain the stream when they grow their workspaces (first call at a larger shape)
  *
  * Three layers:
  *   fdm_op_*    single-kernel operators (one launch on the given stream)
@@ -213,6 +223,11 @@ typedef struct fdm_ln_args {
    * stage 2 and stage 1 sees x alone. */
   const float* gamma2; const float* beta2;
   long long y_t_lo_off;               /* split dtype: elements between the hi and lo planes of y_t */
+  /* add_mat shared by the S conditions of a clip (fdm_audio_prepare_conds): add_mat_group > 0 -> row m reads add_mat row
+   * ((m % add_mat_wrap) / add_mat_group) * add_mat_L + m % add_mat_L, i.e. rows are [wrap block][clip][condition][frame]
+   * (add_mat_group = S * L, add_mat_L = L, add_mat_wrap = rows per cond/uncond half, 0 = no wrap) over an add_mat of
+   * [clips * L, d]; 0 = row m reads add_mat row m */
+  int add_mat_L, add_mat_group, add_mat_wrap;
 } fdm_ln_args;
 int fdm_op_layernorm(const fdm_ln_args* a, void* stream);
 
@@ -332,6 +347,16 @@ int fdm_plan_commit(fdm_plan* p, void* stream);
  * and E0 = PE + style (+ emotion; the uncond rows of a CFG plan use emotion_embedd's bias only).                        */
 int fdm_audio_prepare(fdm_plan* p, const float* hub, int B, int N, int fw, const float* style, const float* emo,
                       int L, int cfg, void* stream);
+/* The same for S conditions per clip: the reference's sampler loops the style one-hots of a clip through ddim_sample one
+ * B = 1 call at a time with the SAME audio (samples/sample_diffusion_vocaset.py:71-83; MEAD: emotion x identity,
+ * samples/sample_diffusion_mead.py:67-86).  Here the S conditions of each of the B clips run as B*S rows blocks of ONE step
+ * program: row block (b, s) = "virtual clip" b*S + s.  style [B*S, n_style], emo [B*S, n_emo] or NULL (virtual-clip order);
+ * AF and the C1_l tables are computed once per CLIP (B*L rows) and shared by its S conditions -- only E0 is per condition.
+ * Afterwards the plan's batch is B*S clips: x_T / out / noise of fdm_sample_graph and fdm_denoise_step are
+ * [B*S, L*G, c], Philox noise is keyed by clip0 + b*S + s, and every row block is bit-identical to the B = 1, S = 1 call
+ * with that clip's audio and that condition.  S = 1 is fdm_audio_prepare. */
+int fdm_audio_prepare_conds(fdm_plan* p, const float* hub, int B, int N, int fw, int S, const float* style, const float* emo,
+                            int L, int cfg, void* stream);
 /* One FDM.forward (models/fdm_vocaset.py:54-91): x_t [B, L*G, c] -> x0_hat [B, L*G, c], CFG-mixed
  * (x0u + cfg_scale (x0 - x0u), utiles/classifierfree.py:20-21) when prepared with cfg.  x0_uncond (optional) receives
  * the unconditional rows.  Eager launches of the recorded step program. */
@@ -352,12 +377,15 @@ typedef struct fdm_sample_args {
   int graph_steps;                /* diffusion steps per graph launch; 0 = default */
 } fdm_sample_args;
 int fdm_sample_graph(fdm_plan* p, const fdm_sample_args* a, void* stream);
-/* Plan-time tuning of the GEMM output tiles at the prepared shape (times candidates per call site; changes speed only). */
+/* Plan-time tuning of the GEMM output tiles at the prepared shape (times candidates per call site; changes speed only, every
+ * tile accumulates k in the same order).  Besides this call, fdm_audio_prepare tunes a shape that earlier sampling calls have
+ * run >= 2000 diffusion steps at; fdm_sample_graph never tunes unless fdm_plan_set(p, "tune_lazy", 1).  FDM_TUNE=0 disables
+ * the tuner; FDM_TILE_OVERRIDE="qkv=3,ffn1=2" pins call sites (applied at fdm_audio_prepare, with or without the tuner). */
 int fdm_plan_tune(fdm_plan* p, void* stream);
 /* Introspection / experiments: integer properties by name -- "launches_per_step", "graph_launches" (host graph launches of
  * the last fdm_sample_graph), "fuse_ln3", "rows", "tile.<call site>" (qkv, out, ffn1, ffn2, enc, dec, ...). */
 int fdm_plan_get(fdm_plan* p, const char* key, long long* out);
-int fdm_plan_set(fdm_plan* p, const char* key, long long value);    /* "tile.<call site>" (drops recorded programs), "tune" (0 = off) */
+int fdm_plan_set(fdm_plan* p, const char* key, long long value);    /* "tile.<call site>" (drops recorded programs), "tune" (0 = off), "tune_lazy" (1 = in-call tuning allowed) */
 
 /* ------------------------------------------------------------------------------------------
  * Audio encoder (once per clip: it does not depend on (t, x_t), so the reference's per-step re-run, models/fdm_vocaset.py:59,

@@ -97,5 +97,7 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     assert len(lines) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 2
+    assert rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo"        # self-checking: the line says how many ranks really ran
+    assert rec["parity"]["max_abs"] < 1e-4 and rec["parity"]["dtype"] == "f32"
     a, b = np.load(one), np.load(two)
     assert a.shape == b.shape == (2, 1600, 64) and np.array_equal(a, b)

@@ -128,6 +128,7 @@ def test_plan_layer_argument_validation_without_device():
     assert l.fdm_plan_commit(None, None) == -1
     assert l.fdm_plan_set_weights(None, b"x", 16, 4, None) == -1
     assert l.fdm_audio_prepare(None, 16, 1, 10, 1024, 16, None, 10, 0, None) == -1
+    assert l.fdm_audio_prepare_conds(None, 16, 1, 10, 1024, 8, 16, None, 10, 0, None) == -1
     assert l.fdm_denoise_step(None, 16, 0, 0.0, 16, None, None) == -1
     assert l.fdm_sample_graph(None, C.byref(_lib.SampleArgs()), None) == -1
     assert l.fdm_plan_tune(None, None) == -1

@@ -340,3 +340,99 @@ def test_full_length_mead_cfg_chain_properties():
     plan.tune()
     one = plan.sample_ddpm(xT[1:], ts, seed=9, clip0=1, cfg_scale=2.5)
     assert torch.equal(one[0], a[1]), "clip result depends on the batch it was sampled in"
+
+
+# ---- condition-batched sampling: S conditions per clip in one step program (fdm_audio_prepare_conds) ----
+@pytest.mark.parametrize("preset,dtype,cfg", [("vocaset", F32, False), ("vocaset", F16X3, False), ("vocaset", BF16, False),
+                                              ("mead", F32, True), ("mead", F16X3, False)])
+def test_condition_batched_equals_sequential_b1_calls(preset, dtype, cfg):
+    """The reference's sampler runs the style one-hots of a clip as sequential B = 1 calls with the same audio
+    (samples/sample_diffusion_vocaset.py:71-83).  One call with S conditions per clip: every (clip, condition) block is
+    bit-identical to its own B = 1 call (denoiser pass, DDIM chain, DDPM chain with Philox keyed by clip0 = b*S + s), and
+    within 1e-4 of the oracle on two conditions.  The audio tables are built once per CLIP (shared by its conditions)."""
+    plan, w = plan_for(preset, dtype)
+    p = plan.p
+    B, S, L, t = 2, 4, 23, 417
+    inp = W.synth_inputs(preset, B, L, seed=5)
+    g = torch.Generator().manual_seed(9)
+    style = torch.eye(p.n_style)[torch.randint(0, p.n_style, (B * S,), generator=g)]
+    emo = torch.eye(p.n_emo)[torch.randint(0, p.n_emo, (B * S,), generator=g)] if p.n_emo else None
+    x = torch.randn(B * S, L * p.G, p.c, generator=g)
+    plan.prepare(inp["hub"], style, emo, L=L, cfg=cfg, n_conds=S)
+    assert plan.B == B * S and plan.get("rows") == B * S * L * (2 if cfg else 1)
+    out = plan.denoise(x.to(DEV), t).cpu()
+    ddim = plan.sample_ddim(x.to(DEV), 5).cpu()
+    ts = list(range(999, 989, -1))
+    ddpm = plan.sample_ddpm(x.to(DEV), ts, seed=11, clip0=40).cpu()
+    for (b, s) in ((0, 0), (0, 3), (1, 2)):
+        r = b * S + s
+        e1 = None if emo is None else emo[r:r + 1]
+        plan.prepare(inp["hub"][b:b + 1], style[r:r + 1], e1, L=L, cfg=cfg)
+        assert torch.equal(plan.denoise(x[r:r + 1].to(DEV), t).cpu()[0], out[r]), "denoiser pass differs from the B = 1 call"
+        assert torch.equal(plan.sample_ddim(x[r:r + 1].to(DEV), 5).cpu()[0], ddim[r]), "DDIM chain differs from the B = 1 call"
+        assert torch.equal(plan.sample_ddpm(x[r:r + 1].to(DEV), ts, seed=11, clip0=40 + r).cpu()[0], ddpm[r]), "DDPM chain differs"
+    # vs the oracle (the reference's arithmetic) on two (clip, condition) blocks
+    for (b, s) in ((0, 1), (1, 3)):
+        r = b * S + s
+        e1 = None if emo is None else emo[r:r + 1]
+        ref = FO.fdm_forward(w, preset, inp["hub"][b:b + 1], t, x[r:r + 1], style[r:r + 1], e1, folded=True)
+        if cfg:
+            ref = FO.cfg_mix(ref, FO.fdm_forward(w, preset, inp["hub"][b:b + 1], t, x[r:r + 1], style[r:r + 1], torch.zeros_like(e1), folded=True))
+        assert mad(out[r], ref[0]) < (TOLBF if dtype == BF16 else TOL32)
+
+
+def test_condition_batching_validates_arguments():
+    plan, _ = plan_for("vocaset_tiny", F32)
+    inp = W.synth_inputs("vocaset_tiny", 2, 8, seed=1)
+    from fdm_amd._lib import FdmError
+    with pytest.raises(FdmError):
+        plan.prepare(inp["hub"], inp["style"], L=8, n_conds=3)        # style rows != clips x conditions
+    with pytest.raises(FdmError):
+        plan.prepare(inp["hub"], inp["style"], L=8, n_conds=0)
+
+
+def test_program_cache_never_evicts_a_program_in_use():
+    """sweeping graph_steps fills the 8-entry program cache; the 1-step program fetched first must survive the
+    insertion of the K-step program in the same call (it replays the n_steps % K tail)."""
+    plan, _ = plan_for("vocaset_tiny", F32)
+    L = 12
+    inp = W.synth_inputs("vocaset_tiny", 1, L, seed=2)
+    plan.prepare(inp["hub"], inp["style"], L=L)
+    ts = list(range(999, 999 - 23, -1))
+    ref = plan.sample_ddpm(inp["x"].to(DEV), ts, seed=3, use_graph=False).cpu()
+    for k in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 2, 9):
+        out = plan.sample_ddpm(inp["x"].to(DEV), ts, seed=3, graph_steps=k).cpu()
+        assert torch.equal(out, ref), f"graph_steps={k}"
+
+
+def test_weight_update_rebuilds_tables_without_growing():
+    """fdm_plan_set_weights after a commit releases the commit-time tables; results follow the new weights and
+    device memory does not grow by a model footprint per update."""
+    w = W.make_fdm_weights("vocaset_tiny")
+    plan = DenoiserPlan("vocaset_tiny", w, F32, DEV)
+    L = 10
+    inp = W.synth_inputs("vocaset_tiny", 1, L, seed=4)
+    plan.prepare(inp["hub"], inp["style"], L=L)
+    a = plan.denoise(inp["x"].to(DEV), 500).cpu()
+    import ctypes as C
+    from fdm_amd._lib import check, lib
+    w2 = {k: v.clone() for k, v in w.items()}
+    w2["latent_decoder.weight"] = w2["latent_decoder.weight"] * 2.0
+    torch.cuda.synchronize()
+    base = None
+    for it in range(6):
+        src = w2 if it % 2 == 0 else w
+        t = src["latent_decoder.weight"].contiguous()
+        check(lib().fdm_plan_set_weights(plan.h, b"latent_decoder.weight", t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        plan.prepare(inp["hub"], inp["style"], L=L)
+        out = plan.denoise(inp["x"].to(DEV), 500).cpu()
+        ref = FO.fdm_forward(src, "vocaset_tiny", inp["hub"], 500, inp["x"], inp["style"], None, folded=True)
+        assert mad(out, ref) < TOL32
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info()
+        if it == 1:
+            base = free
+        if it > 1:
+            assert base - free < (1 << 20), f"device memory grew by {(base - free) >> 10} KiB after weight update {it}"
+    assert mad(a, FO.fdm_forward(w, "vocaset_tiny", inp["hub"], 500, inp["x"], inp["style"], None, folded=True)) < TOL32
