@@ -413,6 +413,62 @@ __global__ __launch_bounds__(256) void vq_quant_kernel(const float* z, const flo
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The rest of VectorQuantizer.forward's return tuple (models/lib/quantizer.py:46-61, models/vq_vae_emotion.py:232-249):
+//   min_encodings [rows, K] one-hot of the chosen code, loss = beta * mean((e - z)^2) + mean((e - z)^2) (the two means are the
+//   same number in a forward pass), perplexity = exp(-sum_k p_k log(p_k + 1e-10)), p = mean over rows of min_encodings.
+// Pass 1: one wavefront per row (grid-stride, fixed row -> wave assignment): squared error of the row in a fixed lane order,
+//   accumulated per wave in double; code histogram through integer atomics (exact in any order).  Pass 2: one workgroup sums the
+//   per-workgroup partials in index order and evaluates the two scalars.  Deterministic; not on the sampling path's clock.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vq_stats_partial_kernel(const float* z, const float* codebook, const int* book, const long long* idx,
+                                                               int B, int R, int c, int K, float* min_enc, double* partial, int* hist) {
+  __shared__ double wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long rows = (long long)B * R;
+  double acc = 0.0;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    const int b = (int)(row / R);
+    const int k = (int)idx[row];
+    const float* e = codebook + ((size_t)(book ? book[b] : 0) * K + k) * c;
+    const float* zr = z + (size_t)row * c;
+    float d2 = 0.f;
+    for (int i = lane; i < c; i += 64) { const float d = __fsub_rn(e[i], zr[i]); d2 = __fmaf_rn(d, d, d2); }
+    acc += (double)wave_sum(d2);
+    if (lane == 0) atomicAdd(hist + k, 1);
+    if (min_enc)
+      for (int j = lane; j < K; j += 64) min_enc[(size_t)row * K + j] = (j == k) ? 1.f : 0.f;
+  }
+  if (lane == 0) wsum[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+__global__ __launch_bounds__(256) void vq_stats_final_kernel(const double* partial, int nparts, const int* hist, int K, long long rows, int c,
+                                                             float beta, float* out) {
+  __shared__ double red[256];
+  const int t = threadIdx.x;
+  double s = 0.0;
+  for (int i = t; i < nparts; i += 256) s += partial[i];
+  red[t] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  const double sq = red[0];
+  __syncthreads();
+  double h = 0.0;
+  for (int k = t; k < K; k += 256) {
+    const float pk = (float)hist[k] / (float)rows;                      // torch.mean of a 0/1 column: exact count / rows in fp32
+    h += (double)(pk * logf(pk + 1e-10f));
+  }
+  red[t] = h;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (t < o) red[t] += red[t + o]; __syncthreads(); }
+  if (t == 0) {
+    const float m = (float)(sq / ((double)rows * c));
+    out[0] = __fadd_rn(__fmul_rn(beta, m), m);                         // beta * mean(.) + mean(.)
+    out[1] = expf(-(float)red[0]);
+  }
+}
+
 // ---- evaluation metrics (computer_metrix.py:84-136, metric/metric.py:115-138): HBM-bound reductions -------------------
 // One workgroup per frame: squared vertex error d2 = ((gx-px)^2 + (gy-py)^2) + (gz-pz)^2 (numpy's order over axis 2, so
 // the per-frame maximum is bit-identical to the reference's), over a vertex region (or all vertices when region == NULL).

@@ -485,6 +485,7 @@ struct fdm_vq {
   float *x32 = nullptr, *c32 = nullptr, *h = nullptr, *hb = nullptr, *h2 = nullptr, *em = nullptr, *xpad32 = nullptr;
   void *xt = nullptr, *y = nullptr, *xp = nullptr, *nt = nullptr, *q = nullptr, *kp = nullptr, *vp = nullptr, *ctx = nullptr, *u = nullptr, *a = nullptr, *xpt = nullptr;
   int* book = nullptr;
+  double* stat_partial = nullptr; int* stat_hist = nullptr;      // fdm_vq_quant_stats scratch
 };
 
 namespace {
@@ -600,6 +601,7 @@ int vq_reserve(fdm_vq* V, int B, int L) {
   FCK(V->ws.alloc(&V->q, M * d * es)); FCK(V->ws.alloc(&V->ctx, M * d * es)); FCK(V->ws.alloc(&V->a, M * d * es)); FCK(V->ws.alloc(&V->u, M * VQ_FFN * es));
   FCK(V->ws.alloc(&V->kp, (size_t)B * kv_pad(L) * d * es, true)); FCK(V->ws.alloc(&V->vp, (size_t)B * kv_pad(L) * d * es, true));
   FCK(V->ws.alloc_t(&V->book, (size_t)B));
+  FCK(V->ws.alloc_t(&V->stat_partial, (size_t)1024)); FCK(V->ws.alloc_t(&V->stat_hist, (size_t)V->d.K));
   if (V->has_encoder) { FCK(V->ws.alloc_t(&V->xpad32, M * V->Kp)); FCK(V->ws.alloc(&V->xpt, M * V->Kp * es)); }
   V->capB = B; V->capL = L;
   return FDM_OK;
@@ -699,6 +701,22 @@ int fdm_vq_quant(fdm_vq* V, const float* z, const float* emo_one_hot, int B, int
     book = V->book;
   }
   return fdm_op_vq_quant(z, V->codebook, book, B, R, V->d.c, V->d.K, zq_bcl, idx, stream);
+}
+
+int fdm_vq_quant_stats(fdm_vq* V, const float* z, const float* emo_one_hot, const long long* idx, int B, int R, float beta,
+                       float* min_encodings, float* out2, void* stream) {
+  if (!V || !z || !idx || !out2) return fail(FDM_ERR_ARG, "vq_quant_stats: null argument");
+  if (B < 1 || R < 1) return fail(FDM_ERR_SHAPE, "vq_quant_stats: bad shape");
+  if (V->d.n_books > 1 && !emo_one_hot) return fail(FDM_ERR_ARG, "vq_quant_stats: this model needs the emotion one-hot to pick the codebook slice");
+  if (!fdm_device_ok()) return fail(FDM_ERR_STATE, "vq_quant_stats: no gfx950 device visible (there is no CPU fallback)");
+  FCK(vq_commit(V, stream));
+  FCK(vq_reserve(V, B, 2));
+  const int* book = nullptr;
+  if (V->d.n_books > 1) {
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, emo_one_hot, V->book, B, V->d.n_books);
+    book = V->book;
+  }
+  return fdm_op_vq_stats(z, V->codebook, book, idx, B, R, V->d.c, V->d.K, beta, min_encodings, V->stat_partial, V->stat_hist, out2, stream);
 }
 
 int fdm_vq_decode(fdm_vq* V, const float* zq_bcl, int B, int R, float* out, void* stream) {

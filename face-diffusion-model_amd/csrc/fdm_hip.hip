@@ -2,6 +2,7 @@
 // the boundary, no allocation or synchronisation inside fdm_op_* (so a caller may capture them).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -347,6 +348,21 @@ int fdm_op_vq_quant(const float* z, const float* codebook, const int* book, int 
     hipLaunchKernelGGL(fdm::vq_quant_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, z, codebook, book, B, R, c, K, zq_bcl, idx);
     return hipGetLastError();
   }, stream, "vq_quant");
+}
+
+int fdm_op_vq_stats(const float* z, const float* codebook, const int* book, const long long* idx, int B, int R, int c, int K, float beta,
+                    float* min_encodings, double* partial, int* hist, float* out, void* stream) {
+  if (!z || !codebook || !idx || !partial || !hist || !out) return fail(FDM_ERR_ARG, "vq_stats: null operand");
+  if (B <= 0 || R <= 0 || K <= 0 || c <= 0) return fail(FDM_ERR_SHAPE, "vq_stats: bad shape");
+  const long long rows = (long long)B * R;
+  const int nblk = (int)std::min<long long>(1024, (rows + 3) / 4);
+  return submit([=](hipStream_t s) {
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)K * sizeof(int), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fdm::vq_stats_partial_kernel, dim3(nblk), dim3(256), 0, s, z, codebook, book, idx, B, R, c, K, min_encodings, partial, hist);
+    hipLaunchKernelGGL(fdm::vq_stats_final_kernel, dim3(1), dim3(256), 0, s, (const double*)partial, nblk, (const int*)hist, K, rows, c, beta, out);
+    return hipGetLastError();
+  }, stream, "vq_stats");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -576,6 +576,285 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large-M main loop ("ping-pong", round 3).  With thousands of rows a workgroup's k loop is no longer a latency chain but
+// a throughput problem: per 64-deep k-tile a 256x128 bf16 tile needs 48 LDS-DMA pieces (each costs its issuing wave
+// 60-185 cycles of issue, MI355X_MICROARCH.md) and 128 fragment reads beside 256 MFMAs.  In gemm_glds_kernel all eight waves
+// do these three things in lockstep behind one barrier per k-tile, so the matrix pipes idle while every wave issues DMA and
+// waits for its fragments (measured at M = 6400: 17-26 % of the MFMA peak in every tile).
+// Here the eight waves form two groups of four (waves w and w + 4 share a SIMD) that run the SAME program half a period
+// apart: while group 0 computes tile kt (32 MFMAs per wave, nothing else), group 1 reads its fragments of tile kt from LDS
+// and issues its share of the DMA for tile kt + D; then they swap.  A SIMD's matrix pipe always has one wave feeding it
+// and the other wave's LDS / DMA issue beside it (matrix beside memory: the complementary pairing of
+// MI355X_MICROARCH.md "Two waves per SIMD", item 5).  Slots are separated by raw s_barriers; group 1 enters the loop one
+// barrier late and group 0 pays one extra barrier at the end.
+//   slot 2kt   : G0 LOAD(kt)     | G1 COMPUTE(kt-1)
+//   slot 2kt+1 : G0 COMPUTE(kt)  | G1 LOAD(kt)
+//   LOAD(kt)   = ds_read the wave's fragments of tile kt (one register set: the previous COMPUTE has consumed it),
+//                issue its pieces of tile kt + D into stage (kt + D) % NST, D = NST - 1
+//   landing    : a wave's counted vmcnt for its pieces of tile kt + 1 sits before the barrier that ends the slot in which
+//                BOTH groups still have to read tile kt + 1 (G0: end of COMPUTE(kt), G1: end of LOAD(kt))
+//   reuse      : stage (kt + D) % NST last held tile kt + D - NST = kt - 1, read in slots 2kt-2 (G0) and 2kt-1 (G1): both
+//                lie before slot 2kt, the first slot that issues into it
+// Same operands, same LDS image (lane-linear DMA, source-side XOR swizzle), same k order per accumulator and the same
+// epilogue as gemm_glds_kernel: results are bit-identical to every other tile.
+// ---------------------------------------------------------------------------------------------------
+#ifndef FDM_PP_PRIO
+#define FDM_PP_PRIO 1         // experiments: 0 = no s_setprio, 1 = raised around the MFMA cluster, 2 = raised around the LOAD phase
+#endif
+#ifndef FDM_PP_VARIANT
+#define FDM_PP_VARIANT 0      // tools/pp_probe.cpp only: bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no DMA after the prologue
+#endif
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool HEAVY = false, bool SCHED = false, int SPEC = 0>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
+  using E = typename Opnd<T>::E;
+  static_assert(WM * WN == 8, "ping-pong loop: two groups of four waves");
+  constexpr int NP = Opnd<T>::NP;
+  constexpr int KCH = 8, NW = 8, ROWB = 128, RPI = 8;
+  constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+  constexpr int A_IPW = BM / RPI / NW, W_IPW = BN / RPI / NW;
+  static_assert(A_IPW >= 1 && W_IPW >= 1 && MI >= 1 && NI >= 1, "tile too small for the wave grid");
+  constexpr int P = NP * (A_IPW + W_IPW);          // DMA pieces per wave and k-tile
+  constexpr int D = NST - 1;                       // k-tiles in flight
+  constexpr int STAGE = NP * (BM + BN) * ROWB;
+  static_assert(NST >= 2 && NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>(), "epilogue staging does not fit in the ring");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* rowstat = (float*)(smem + NST * STAGE);
+#ifdef FDM_PP_PHASES
+  const unsigned long long t_entry = wall_clock64();
+#endif
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    const int nv = *p.incr_counter + 1;
+    *p.incr_counter = nv;
+    if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];
+  }
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                       // waves w and w + 4 share a SIMD (cyclic placement)
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = lane >> 4, r16 = lane & 15;
+  const int z = blockIdx.z;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so consecutive ids land on different L2s.
+  // Give each XCD a contiguous run of tiles, column-tile fastest: the tiles of one row block (same A rows) share an L2.
+  const int gx = gridDim.x, gy = gridDim.y, nwg = gx * gy;
+  int bid = blockIdx.y * gx + blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective for any nwg
+  }
+  const int m0 = (bid / gx) * BM, n0 = (bid % gx) * BN;
+  const int M = p.M, N = p.N;
+  const E* A = (const E*)p.A + (size_t)z * p.a_batch_stride;
+  const E* W = (const E*)p.W + (size_t)z * p.w_batch_stride;
+  const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);
+
+  const int lrow = lane / KCH, slot = lane % KCH;
+  const char* a_src[A_IPW];
+  const char* w_src[W_IPW];
+#pragma unroll
+  for (int i = 0; i < A_IPW; ++i) {
+    const int row = RPI * (wave * A_IPW + i) + lrow;
+    a_src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * p.lda) + ((slot ^ (row % KCH)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < W_IPW; ++i) {
+    const int row = RPI * (wave * W_IPW + i) + lrow;
+    w_src[i] = (const char*)(W + (size_t)min(n0 + row, N - 1) * p.ldw) + ((slot ^ (row % KCH)) << 4);
+  }
+  auto issue = [&](int kt) {
+    char* sb = smem + (kt % NST) * STAGE;
+    const size_t off = (size_t)kt * ROWB;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+      for (int i = 0; i < A_IPW; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (wave * A_IPW + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < W_IPW; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + off + pl * w_lo), (lptr_t)(sb + (NP * BM + pl * BN) * ROWB + (wave * W_IPW + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MI][NI];
+  f32x4 accl[NP == 2 ? MI : 1][NP == 2 ? NI : 1];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if constexpr (NP == 2) accl[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  constexpr int EPC = 16 / (int)sizeof(E);
+  const int nk = p.K / (KCH * EPC);
+#pragma unroll
+  for (int t = 0; t < D; ++t)
+    if (t < nk) issue(t);
+  constexpr bool FOLDC = !(SPEC & GEMM_LEAN) || (SPEC & GEMM_FOLD);
+  if constexpr (FOLDC) gemm_load_rowstats<BM>(p, m0, rowstat);
+
+  // per-lane LDS byte offsets of the fragment reads (k-step 0); k-step 1 flips chunk bit 2: (4 + g) ^ r = (g ^ r) ^ 4
+  int a_off[MI], w_off[NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int row = wm * (BM / WM) + mi * 16 + r16;
+    a_off[mi] = row * ROWB + ((g ^ (row % KCH)) << 4);
+  }
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    const int row = wn * (BN / WN) + ni * 16 + r16;
+    w_off[ni] = (NP * BM + row) * ROWB + ((g ^ (row % KCH)) << 4);
+  }
+  u32x4 af[2][MI][NP], wf[2][NI][NP];
+  auto load_frags = [&](int kt) {
+    const char* base = smem + (kt % NST) * STAGE;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[s][mi][pl] = *(const u32x4*)(base + pl * BM * ROWB + (a_off[mi] ^ (s << 6)));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wf[s][ni][pl] = *(const u32x4*)(base + pl * BN * ROWB + (w_off[ni] ^ (s << 6)));
+      }
+  };
+#ifdef FDM_PP_MFMA32
+  // timing experiment only (results are garbage): the same registers fed to 32x32x16 MFMAs -- half the A/B operand fetches per flop
+  typedef __attribute__((ext_vector_type(16))) float f32x16;
+  f32x16 acc32[MI / 2][NI / 2];
+#pragma unroll
+  for (int a_ = 0; a_ < MI / 2; ++a_)
+#pragma unroll
+    for (int b_ = 0; b_ < NI / 2; ++b_)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc32[a_][b_][j] = 0.f;
+#endif
+  auto compute = [&]() {
+#ifdef FDM_PP_MFMA32
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int a_ = 0; a_ < MI / 2; ++a_)
+#pragma unroll
+          for (int b_ = 0; b_ < NI / 2; ++b_)
+            acc32[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s][2 * b_ + hh][0]), __builtin_bit_cast(bf16x8, af[s][2 * a_ + hh][0]), acc32[a_][b_], 0, 0, 0);
+    return;
+#endif
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          if constexpr (NP == 1) {
+            Mma<T>::run(acc[mi][ni], wf[s][ni][0], af[s][mi][0]);
+          } else {
+            mma16<E>(acc[mi][ni], wf[s][ni][0], af[s][mi][0]);
+            mma16<E>(accl[mi][ni], wf[s][ni][0], af[s][mi][1]);
+            mma16<E>(accl[mi][ni], wf[s][ni][1], af[s][mi][0]);
+          }
+        }
+  };
+
+  // tile 0 has landed once at most the D - 1 younger tiles of this wave are still in flight
+  if (D - 1 < nk) wait_vmcnt<(D - 1) * P>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (grp) __builtin_amdgcn_s_barrier();            // group 1 runs one slot behind group 0
+#ifdef FDM_PP_PHASES
+  // tools/pp_probe.cpp: 100 MHz wall-clock stamps of every workgroup -> p.rln_gamma as [workgroup][4] u64: entry, loop start, loop end, stores done
+  unsigned long long* phases = (tid == 0) ? (unsigned long long*)p.rln_gamma + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 4 : nullptr;
+  if (phases) { phases[0] = t_entry; phases[1] = wall_clock64(); }
+#endif
+#ifdef FDM_PP_STAMPS
+  // tools/pp_probe.cpp: shader-clock stamps of one workgroup's waves around every slot -> p.rln_beta as [wave][kt < 16][4] u64
+  unsigned long long* stamps = (blockIdx.x == 1 && blockIdx.y == 3 && lane == 0) ? (unsigned long long*)p.rln_beta + (size_t)wave * 64 : nullptr;
+#define PP_STAMP(i) do { if (stamps && kt < 16) stamps[kt * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PP_STAMP(i) do { } while (0)
+#endif
+  for (int kt = 0; kt < nk; ++kt) {
+    // ---- LOAD(kt)
+    PP_STAMP(0);
+    if constexpr (FDM_PP_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(FDM_PP_VARIANT & 2)) load_frags(kt);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!(FDM_PP_VARIANT & 4)) { if (kt + D < nk) issue(kt + D); }
+    if (grp) {                                      // own pieces of tile kt + 1 landed (group 0 waits after its COMPUTE)
+      if (kt + D < nk) wait_vmcnt<(D - 1) * P>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FDM_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+    PP_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    // ---- COMPUTE(kt)
+    PP_STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FDM_PP_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (!(FDM_PP_VARIANT & 1)) {
+      compute();
+    } else if constexpr (!(FDM_PP_VARIANT & 2)) {      // keep the fragment reads alive
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(af[s][mi][0]));
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) asm volatile("" ::"v"(wf[s][ni][0]));
+      }
+    }
+    if constexpr (FDM_PP_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    if (!grp) {
+      if (kt + D < nk) wait_vmcnt<(D - 1) * P>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    PP_STAMP(3);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (!grp) __builtin_amdgcn_s_barrier();           // matches group 1's late start
+#ifdef FDM_PP_PHASES
+  if (phases) phases[2] = wall_clock64();
+#endif
+#ifdef FDM_PP_MFMA32
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[mi][ni][j] = acc32[mi / 2][ni / 2][(mi & 1) * 8 + (ni & 1) * 4 + j];
+#endif
+  if constexpr (NP == 2) {
+    constexpr float inv = 1.f / Opnd<T>::SCALE;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) acc[mi][ni] += accl[mi][ni] * inv;
+  }
+  // the epilogue operands are fetched after the k loop here (one exposed round trip per workgroup, against 16+ k-tiles of
+  // work): held across the loop they would cost MI * NI * 4 registers beside the accumulators and the fragment set
+  EpiPre<MI, NI> epre;
+  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
+  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+#ifdef FDM_PP_PHASES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (phases) phases[3] = wall_clock64();
+#endif
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool HEAVY, bool SCHED = false, int SPEC = 0>
+static hipError_t gemm_pp_launch_h(const fdm_gemm_args& a, hipStream_t s) {
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
+  constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * 128 + gemm_ln_scratch_bytes<BM, BN>();
+  static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
+  static bool once = [] {
+    return hipFuncSetAttribute((const void*)gemm_pp_kernel<T, BM, BN, WM, WN, NST, HEAVY, SCHED, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+  }();
+  (void)once;
+  hipLaunchKernelGGL((gemm_pp_kernel<T, BM, BN, WM, WN, NST, HEAVY, SCHED, SPEC>), grid, dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false, int SPEC = 0>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
@@ -625,6 +904,23 @@ static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
   return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false>(a, s);
 }
 
+template <typename T, int BM, int BN, int WM, int WN, int NST>
+static hipError_t gemm_pp_launch_t(const fdm_gemm_args& a, hipStream_t s) {
+  if (gemm_act_is_heavy(a.act)) {
+    if (!a.out_kp && !a.out_vp && !a.stat_out && !a.ln_stat_in && gemm_all_tiles_lean<T, BM, BN>(a))
+      return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, true, false, GEMM_LEAN>(a, s);
+    return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, true>(a, s);
+  }
+  if (gemm_all_tiles_lean<T, BM, BN>(a)) {
+    const bool kv = a.out_kp || a.out_vp, fold = a.stat_out || a.ln_stat_in;
+    if (kv && fold) return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, false, false, GEMM_LEAN | GEMM_KV | GEMM_FOLD>(a, s);
+    if (kv) return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, false, false, GEMM_LEAN | GEMM_KV>(a, s);
+    if (fold) return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, false, false, GEMM_LEAN | GEMM_FOLD>(a, s);
+    return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, false, false, GEMM_LEAN>(a, s);
+  }
+  return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, false>(a, s);
+}
+
 // Tile choice: fdm_gemm_args.tile (the caller's plan-time choice), else the FDM_GEMM_TILE override (env, read once: the
 // FDM_TILE_* value forced for every GEMM, for A/B measurements), else a heuristic on the tile count.
 static int gemm_tile_override() {
@@ -649,6 +945,7 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
     case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 32 KB -> 4 workgroups per CU
     case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);    // 4 waves, 16x32 per wave, 36 KB
+    case FDM_TILE_256x128_PP: return gemm_pp_launch_t<T, 256, 128, 4, 2, 3>(a, s);   // ping-pong loop, 64x64 per wave, 146 KB
     default: break;
   }
   // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;

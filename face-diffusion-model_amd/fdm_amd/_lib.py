@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
                 ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll)]
 
 
-TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 class ModelDesc(C.Structure):
@@ -94,6 +94,7 @@ SYMBOLS = {
     "fdm_op_mean_diff": (ci, [vp, vp, vp, vp, ll, ci, vp]),
     "fdm_op_time_groupnorm": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, ci, vp]),
     "fdm_op_vq_quant": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
+    "fdm_op_vq_stats": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]),
     "fdm_prog_create": (ci, [C.POINTER(vp)]),
     "fdm_prog_destroy": (ci, [vp]),
     "fdm_prog_begin": (ci, [vp]),
@@ -125,6 +126,7 @@ SYMBOLS = {
     "fdm_vq_create": (ci, [C.POINTER(VqDesc), ci, C.POINTER(vp)]),
     "fdm_vq_set_weights": (ci, [vp, C.c_char_p, vp, ll, vp]),
     "fdm_vq_quant": (ci, [vp, vp, vp, ci, ci, vp, vp, vp]),
+    "fdm_vq_quant_stats": (ci, [vp, vp, vp, vp, ci, ci, cf, vp, vp, vp]),
     "fdm_vq_decode": (ci, [vp, vp, ci, ci, vp, vp]),
     "fdm_vq_encode": (ci, [vp, vp, vp, ci, ci, vp, vp]),
     "fdm_vq_destroy": (ci, [vp]),

@@ -515,13 +515,12 @@ class VQAutoEncoder(ParamTree):
         return self.plan(x.device).encode(x, emo)
 
     def quant(self, x, one_hot=None):
-        """-> (z_q [B, c, L*G], emb_loss, (perplexity, min_encodings, indices)); the training-only
-        outputs (loss, perplexity, one-hot encodings) are not produced on the sampling path (None)."""
+        """-> (z_q [B, c, L*G], emb_loss, (perplexity, min_encodings [B*L*G, 256], indices [B*L*G, 1])): the reference's
+        whole tuple (models/vq_vae_vocaset.py:31-33 -> models/lib/quantizer.py:35-64, beta = 0.25), all of it on the device."""
         if not x.is_cuda:
             raise FdmError("VQAutoEncoder.quant runs on the HIP path only")
         emo = None if one_hot is None else one_hot.reshape(-1, one_hot.shape[-1])
-        zq, idx = self.plan(x.device).quant(x, emo)
-        return zq, None, (None, None, idx)
+        return self.plan(x.device).quant_full(x, emo, beta=0.25)
 
     def decode(self, quant):
         if not quant.is_cuda:

@@ -103,6 +103,22 @@ class VQPlan:
         self._in = (z, em)
         return zq, idx
 
+    def quant_full(self, z, emo=None, beta=0.25, min_encodings=True):
+        """The reference's whole quant() tuple (models/lib/quantizer.py:35-64, models/vq_vae_vocaset.py:16-18,31-33):
+        (z_q [B, c, R], emb_loss, (perplexity, min_encodings [B*R, 256], indices [B*R, 1]))."""
+        from ._lib import check, lib
+        zq, idx = self.quant(z, emo)
+        z_, em = self._in
+        B, R, _ = z_.shape
+        dv = self.device
+        me = torch.empty(B * R, self.p.K, device=dv) if min_encodings else None
+        out2 = torch.empty(2, device=dv)
+        with torch.cuda.device(dv):
+            check(lib().fdm_vq_quant_stats(self.h, z_.data_ptr(), em.data_ptr() if em is not None else None, idx.data_ptr(), B, R,
+                                           float(beta), me.data_ptr() if me is not None else None, out2.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream))
+        return zq, out2[0], (out2[1], me, idx)
+
     def decode(self, zq):
         """zq [B, c, L*G] -> vertex offsets [B, L, V3] fp32 (template is added by the caller)."""
         from ._lib import check, lib

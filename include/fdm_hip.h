@@ -161,7 +161,8 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_128x64_S3 7  /* 128x64 with a 3-stage ring (two workgroups per CU) */
 #define FDM_TILE_64x64_S2 8   /* 64x64 with a 2-stage ring (four workgroups per CU) */
 #define FDM_TILE_32x64_S3 9   /* 32x64 on 4 waves, 3-stage ring: twice the workgroups of 64x64 for few-hundred-row GEMMs */
-#define FDM_TILE_MAX 9
+#define FDM_TILE_256x128_PP 10 /* 256x128, two wave groups half a period apart (one computes while the other loads): large M */
+#define FDM_TILE_MAX 10
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -284,6 +285,12 @@ int fdm_op_group_pad(const void* in, void* out, int B, int T, int d, int groups,
  * permuted to [B, c, R] (R = L*G rows per clip).  book[b] selects the 256-code slice.        */
 int fdm_op_vq_quant(const float* z, const float* codebook, const int* book, int B, int R, int c, int K,
                     float* zq_bcl, long long* idx, void* stream);
+/* The rest of VectorQuantizer.forward's return tuple (models/lib/quantizer.py:46-61; EVQ models/vq_vae_emotion.py:232-249) for the
+ * indices idx [B*R] fdm_op_vq_quant chose: min_encodings [B*R, K] one-hot fp32 (optional), out[0] = loss =
+ * beta * mean((e - z)^2) + mean((e - z)^2), out[1] = perplexity = exp(-sum_k p_k log(p_k + 1e-10)), p = column means of
+ * min_encodings.  partial: >= 1024 doubles, hist: K ints of scratch.  Deterministic (fixed reduction order, integer histogram). */
+int fdm_op_vq_stats(const float* z, const float* codebook, const int* book, const long long* idx, int B, int R, int c, int K, float beta,
+                    float* min_encodings, double* partial, int* hist, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Step programs: record fdm_op_* calls, run them eagerly or as a hipGraph replayed n times.  */
@@ -411,7 +418,8 @@ int fdm_hubert_destroy(fdm_audio_encoder* e);
  * Geometry from the reference's *_vq_vae_args (models/utils/config.py): G = face_quan_num, c = zquant_dim, K = 256 codes
  * per book, n_books = n_embed / 256 (emotion-sliced codebook), V3 = in_dim; pre = decoder_linear_embedding_pre /
  * encoder_linear_embedding_post present (3D-MEAD, BIWI).  Weights by reference state-dict name.
- * quant:  z [B, R, c] (+ emotion one-hot [B, n_books]) -> z_q [B, c, R] (the reference's permuted output), idx [B*R] int64
+ * quant:  z [B, R, c] (+ emotion one-hot [B, n_books]) -> z_q [B, c, R] (the reference's permuted output), idx [B*R] int64;
+ *         quant_stats: emb_loss, perplexity, min_encodings of that call
  * decode: z_q [B, c, L*G] -> vertex offsets [B, L, V3] (the caller adds the template; every clip gets pe[0], a20)
  * encode: x [B, L, V3] (+ emotion one-hot [B, 7]) -> latent [B, L*G, c]                                                  */
 typedef struct fdm_vq_desc { int G, c, K, n_books, V3, pre; } fdm_vq_desc;
@@ -419,6 +427,10 @@ typedef struct fdm_vq fdm_vq;
 int fdm_vq_create(const fdm_vq_desc* desc, int dtype, fdm_vq** out);
 int fdm_vq_set_weights(fdm_vq* v, const char* name, const float* ptr, long long n, void* stream);
 int fdm_vq_quant(fdm_vq* v, const float* z, const float* emo_one_hot, int B, int R, float* zq_bcl, long long* idx, void* stream);
+/* emb_loss, perplexity and min_encodings of the same call (the reference returns them from quant(): models/vq_vae_vocaset.py:31-33,
+ * beta = 0.25 :16-18): out2 = {loss, perplexity} device floats, min_encodings [B*R, K] device fp32 or NULL. */
+int fdm_vq_quant_stats(fdm_vq* v, const float* z, const float* emo_one_hot, const long long* idx, int B, int R, float beta,
+                       float* min_encodings, float* out2, void* stream);
 int fdm_vq_decode(fdm_vq* v, const float* zq_bcl, int B, int R, float* out, void* stream);
 int fdm_vq_encode(fdm_vq* v, const float* x, const float* emo_one_hot, int B, int L, float* latent, void* stream);
 int fdm_vq_destroy(fdm_vq* v);

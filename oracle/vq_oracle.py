@@ -35,6 +35,25 @@ def quant(w, preset, z, emo=None):
     return zq.permute(0, 2, 1).contiguous(), idx.reshape(-1, 1)
 
 
+def quant_stats(w, preset, z, emo=None, beta=0.25):
+    """The rest of VectorQuantizer.forward's tuple for a B = 1 call (quantizer.py:46-61; EVQ vq_vae_emotion.py:232-249):
+    min_encodings [R, 256] one-hot, loss = beta * mean((z_q - z)^2) + mean((z_q - z)^2), perplexity =
+    exp(-sum(e_mean * log(e_mean + 1e-10))), e_mean = mean(min_encodings, dim=0).  -> (loss, perplexity, min_encodings)."""
+    p = PRESETS[preset]
+    E = w["quantize.embedding.weight"]
+    Eb = E
+    if p["n_books"] > 1:
+        pos = int(torch.argmax(emo.reshape(-1, emo.shape[-1])[0]))
+        Eb = E[pos * 256:(pos + 1) * 256]
+    _, idx = quant(w, preset, z, emo)
+    me = torch.zeros(idx.shape[0], 256)
+    me.scatter_(1, idx, 1)
+    z_q = torch.matmul(me, Eb).view(z.shape)
+    loss = beta * torch.mean((z_q - z) ** 2) + torch.mean((z_q - z) ** 2)
+    e_mean = torch.mean(me, dim=0)
+    return loss, torch.exp(-torch.sum(e_mean * torch.log(e_mean + 1e-10))), me
+
+
 def gelu_tanh(x):
     """models/utils/base_model_util.py:81-94."""
     cdf = 0.5 * (1.0 + torch.tanh((np.sqrt(2 / np.pi) * (x + 0.044715 * torch.pow(x, 3)))))

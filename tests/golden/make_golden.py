@@ -437,6 +437,38 @@ def g11_wav2vec():
     save("wav2vec", **out)
 
 
+def g15_vq_stats():
+    """The whole return tuple of the reference's quant(): emb_loss, perplexity and the code histogram of min_encodings
+    (its column sums; the one-hot matrix itself is the indices of vq.npz) -- VectorQuantizer.forward, quantizer.py:35-64."""
+    from models.utils.config import vocaset_vq_vae_args, vq_vae_args, biwi_vq_vae_args
+    from models.vq_vae_vocaset import VQAutoEncoder as V1
+    from models.vq_vae_emotion import VQAutoEncoder as V2
+    from models.vq_vae import VQAutoEncoder as V3
+    out = {}
+    for preset, V, args in (("vocaset", V1, vocaset_vq_vae_args()), ("mead", V2, vq_vae_args()), ("biwi", V3, biwi_vq_vae_args())):
+        p = W.PRESETS[preset]
+        ae = V(args).eval()
+        wd = W.make_vq_weights(preset)
+        check_load(ae, wd)
+        for L in (5, 100):
+            g = torch.Generator().manual_seed(140 + L)
+            z = torch.randn(1, L * p["G"], p["c"], generator=g) * (1.5 / 256)
+            for e in ([0, 5] if p["n_books"] > 1 else [0]):
+                emo = torch.eye(7)[e] if p["n_books"] > 1 else None
+                with torch.no_grad():
+                    zq, loss, info = ae.quant(z, emo) if p["n_books"] > 1 else ae.quant(z)
+                ol, op_, ome = VO.quant_stats(wd, preset, z, None if emo is None else emo.unsqueeze(0))
+                key = f"{preset}_L{L}_e{e}"
+                print(f"  {key}: loss {float(loss):.6e} (oracle {float(ol):.6e})  perplexity {float(info[0]):.5f} (oracle {float(op_):.5f})  "
+                      f"min_encodings equal={bool(torch.equal(info[1], ome))}")
+                out[key + "_loss"] = np.array(float(loss), dtype=np.float32)
+                out[key + "_perplexity"] = np.array(float(info[0]), dtype=np.float32)
+                out[key + "_hist"] = info[1].sum(0).numpy().astype(np.int32)
+                out[key + "_idx"] = info[2].numpy().astype(np.int16)
+                assert tuple(info[1].shape) == (z.shape[1], 256)
+    save("vq_stats", **out)
+
+
 def g12_vq_encode():
     """VQ-VAE encoders: encode -> quant -> decode round trip on the reference."""
     from models.utils.config import vocaset_vq_vae_args, vq_vae_args, biwi_vq_vae_args
@@ -582,7 +614,7 @@ ALL = {
     "chains_vocaset": lambda: g4_chains("vocaset"),
     "chains_mead": lambda: g4_chains("mead"),
     "chains_vocaset_tiny": lambda: g4_chains("vocaset_tiny"),
-    "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio, "state_keys": g10_state_keys, "wav2vec": g11_wav2vec, "vq_encode": g12_vq_encode,
+    "cfg1_e2e": g5_cfg1, "hubert": g6_hubert, "vq": g7_vq, "cfg_mead": g8_cfg, "audio_misc": g9_audio, "state_keys": g10_state_keys, "wav2vec": g11_wav2vec, "vq_encode": g12_vq_encode, "vq_stats": g15_vq_stats,
     "metrics": g13_metrics, "hubert_frames": g14_hubert_frames,
 }
 

@@ -108,6 +108,50 @@ def test_vq_quant_decode_vs_golden(golden, preset, L, e):
         assert mad(dec[:, ::16], g[key + "_dec_cols16"]) < 1e-4
 
 
+@pytest.mark.parametrize("preset,L,e", [("vocaset", 5, 0), ("vocaset", 100, 0), ("mead", 5, 5), ("mead", 100, 0), ("mead", 100, 5), ("biwi", 5, 0), ("biwi", 100, 0)])
+def test_vq_quant_returns_the_reference_tuple(golden, preset, L, e):
+    """quant() -> (z_q, emb_loss, (perplexity, min_encodings, indices)) like the reference's (models/lib/quantizer.py:52-64, EVQ
+    models/vq_vae_emotion.py:240-252): loss and perplexity against the values the reference returned (tests/golden/vq_stats.npz),
+    min_encodings one-hot of the reference's indices; also through the VQAutoEncoder module surface."""
+    g = golden("vq_stats")
+    p = W.PRESETS[preset]
+    gen = torch.Generator().manual_seed(140 + L)
+    z = torch.randn(1, L * p["G"], p["c"], generator=gen) * (1.5 / 256)
+    emo = torch.eye(7)[e].unsqueeze(0) if p["n_books"] > 1 else None
+    key = f"{preset}_L{L}_e{e}"
+    zq, loss, (perp, me, idx) = vq_plan(preset).quant_full(z, emo)
+    gi = torch.from_numpy(g[key + "_idx"].astype(np.int64))
+    assert torch.equal(idx.cpu(), gi), key
+    assert tuple(me.shape) == (L * p["G"], 256) and torch.equal(me.cpu().argmax(1, keepdim=True), gi)
+    assert float(me.sum()) == L * p["G"] and np.array_equal(me.sum(0).cpu().numpy().astype(np.int32), g[key + "_hist"])
+    assert abs(float(loss) / float(g[key + "_loss"]) - 1) < 1e-5, (float(loss), float(g[key + "_loss"]))
+    assert abs(float(perp) / float(g[key + "_perplexity"]) - 1) < 1e-5, (float(perp), float(g[key + "_perplexity"]))
+    ozq, _ = VO.quant(W.make_vq_weights(preset), preset, z, emo)
+    assert torch.equal(zq.cpu(), ozq)
+    # batched: B = 3 clips, statistics over all rows (build-defined B > 1: the reference runs bs = 1)
+    z3 = torch.cat([z, z * 0.5, z * 1.5])
+    e3 = None if emo is None else emo.expand(3, -1)
+    _, loss3, (perp3, me3, idx3) = vq_plan(preset).quant_full(z3, e3)
+    wts = W.make_vq_weights(preset)
+    E = wts["quantize.embedding.weight"]
+    Eb = E[e * 256:(e + 1) * 256] if p["n_books"] > 1 else E
+    d2 = (Eb[idx3.cpu()[:, 0]] - z3.reshape(-1, p["c"])) ** 2
+    assert abs(float(loss3) / float(1.25 * d2.double().mean()) - 1) < 1e-5
+    pk = torch.bincount(idx3.cpu()[:, 0], minlength=256).double() / idx3.shape[0]
+    assert abs(float(perp3) / float(torch.exp(-(pk * torch.log(pk + 1e-10)).sum())) - 1) < 1e-5
+
+
+def test_vq_module_quant_tuple_shape():
+    from types import SimpleNamespace
+    from fdm_amd.modules import VQAutoEncoder
+    ae = VQAutoEncoder(SimpleNamespace(in_dim=15069, n_embed=256, face_quan_num=16, zquant_dim=64))
+    z = torch.randn(1, 5 * 16, 64, device=DEV) * (1.5 / 256)
+    zq, loss, (perp, me, idx) = ae.quant(z)
+    assert tuple(zq.shape) == (1, 64, 80) and loss.dim() == 0 and perp.dim() == 0
+    assert tuple(me.shape) == (80, 256) and tuple(idx.shape) == (80, 1) and idx.dtype == torch.int64
+    assert float(loss) > 0 and 1.0 <= float(perp) <= 256.0
+
+
 def test_vq_near_ties_against_fixed_order_c_oracle():
     """The HIP kernel and oracle/fdm_oracle_c.c share one documented operation order, so indices are
     bit-identical on every row, crafted near-ties included."""

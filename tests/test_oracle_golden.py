@@ -164,6 +164,30 @@ def test_wav2vec2_base(golden):
     assert mad(WO.wav2vec_forward_clip(W.make_wav2vec_weights(12), wav, 12), g["out_L12_2s"]) < TOL
 
 
+STATS_CASES = [("vocaset", 5, 0), ("vocaset", 100, 0), ("mead", 5, 0), ("mead", 5, 5), ("mead", 100, 0), ("mead", 100, 5), ("biwi", 5, 0), ("biwi", 100, 0)]
+
+
+def vq_stats_case(preset, L, e):
+    p = W.PRESETS[preset]
+    gen = torch.Generator().manual_seed(140 + L)
+    z = torch.randn(1, L * p["G"], p["c"], generator=gen) * (1.5 / 256)
+    emo = torch.eye(7)[e].unsqueeze(0) if p["n_books"] > 1 else None
+    return W.make_vq_weights(preset), z, emo
+
+
+@pytest.mark.parametrize("preset,L,e", STATS_CASES)
+def test_vq_quant_full_tuple(golden, preset, L, e):
+    """emb_loss, perplexity and min_encodings of the reference's quant() (quantizer.py:46-61) as the reference returned them."""
+    g = golden("vq_stats")
+    w, z, emo = vq_stats_case(preset, L, e)
+    key = f"{preset}_L{L}_e{e}"
+    loss, perp, me = VO.quant_stats(w, preset, z, emo)
+    assert float(loss) == pytest.approx(float(g[key + "_loss"]), rel=1e-6)
+    assert float(perp) == pytest.approx(float(g[key + "_perplexity"]), rel=1e-6)
+    assert np.array_equal(me.sum(0).numpy().astype(np.int32), g[key + "_hist"])
+    assert np.array_equal(me.argmax(1).numpy().astype(np.int16), g[key + "_idx"][:, 0])
+
+
 @pytest.mark.parametrize("preset", ["vocaset", "mead", "biwi"])
 def test_vq_encode_round_trip(golden, preset):
     """VQ-VAE encoder: encode -> quant -> decode as the reference's stage-1 round trip."""
