@@ -39,8 +39,13 @@ template <typename T> __device__ __forceinline__ float fexp(float x) {
 // products in three 16-bit MFMA passes (hi.hi into the main accumulator, hi.lo + lo.hi into a second one, combined once per
 // key tile for the scores and once at the end for O); the probabilities are split the same way in registers.  fp32-class
 // results at a fifth of the fp32 kernel's MFMA time and half its key tiles.
+// Split kind at head_dim 256 (BIWI: 4 heads x 256): the fragments of a whole key tile (K 128 + V 128 registers) cannot be held
+// beside Q (64) and the two O^T accumulators (128), so K and V are STREAMED through the products -- K in two halves of the
+// head dim (the score accumulators carry across), V in two halves of the output rows -- at one wave per SIMD (~300 registers).
+template <typename T, int HD> constexpr bool attn_streamed() { return Opnd<T>::NP == 2 && HD == 256; }
+
 template <typename T, int HD, int QS>
-__global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
+__global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_kernel(const fdm_attn_args p) {
   // QS = 16-query sub-tiles per workgroup (1 or 2).  With QS = 2 every K / V^T fragment fetched from L2 feeds
   // two S^T and two O^T products: the kernel is bound by L2 -> register fragment traffic, which this halves.
   using E = typename Opnd<T>::E;
@@ -52,6 +57,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
   constexpr int NSUB = KT / 16;                // 16-key sub-tiles per tile
   constexpr int NC = HD / 16;                  // 16-row chunks of O^T
   constexpr int BQ = 16 * QS;
+  constexpr bool STREAM = attn_streamed<T, HD>();
+  constexpr int KSH = STREAM ? NKS / 2 : NKS;  // k-steps of K held at once
+  constexpr int NCH = STREAM ? NC / 2 : NC;    // O^T chunks whose V fragments are held at once
+  static_assert(!STREAM || QS == 1, "the streamed form runs one query sub-tile");
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, r16 = lane & 15;
@@ -114,27 +123,54 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
   for (int kt = wave; kt < ntiles; kt += 4) {
     const int kbase = kt * KT;
     // fragment-packed K / V: every operand fragment of this key tile is one contiguous 1 KB run
-    u32x4 kcur[NSUB][NKS][NP];
+    u32x4 kcur[NSUB][KSH][NP];
+    auto load_k = [&](int ks0) {
 #pragma unroll
-    for (int s = 0; s < NSUB; ++s)
+      for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
+        for (int ks = 0; ks < KSH; ++ks)
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) kcur[s][ks][pl] = *(const u32x4*)(Kp + pl * kv_lo + (size_t)((kt * NSUB + s) * NKS + ks) * (64 * EPC));
-    u32x4 vf[NC][NP];
+          for (int pl = 0; pl < NP; ++pl) kcur[s][ks][pl] = *(const u32x4*)(Kp + pl * kv_lo + (size_t)((kt * NSUB + s) * NKS + ks0 + ks) * (64 * EPC));
+    };
+    load_k(0);
+    u32x4 vf[NCH][NP];
+    auto load_v = [&](int c0, int c1, int cbase) {
+#pragma unroll
+      for (int c = c0; c < c1; ++c)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) vf[c][pl] = *(const u32x4*)(Vp + pl * kv_lo + (size_t)(kt * NC + cbase + c) * (64 * EPC));
+    };
     // split kind: the second half of V is requested after the scores (into the registers the K fragments free), which
     // keeps the kernel at two waves per SIMD; its latency overlaps the softmax arithmetic
-    constexpr int NC_EARLY = (NP == 2) ? NC / 2 : NC;
-#pragma unroll
-    for (int c = 0; c < NC_EARLY; ++c)
-#pragma unroll
-      for (int pl = 0; pl < NP; ++pl) vf[c][pl] = *(const u32x4*)(Vp + pl * kv_lo + (size_t)(kt * NC + c) * (64 * EPC));
+    constexpr int NC_EARLY = STREAM ? 0 : ((NP == 2) ? NC / 2 : NC);
+    load_v(0, NC_EARLY, 0);
 #pragma unroll
     for (int u = 0; u < QS; ++u) {
       // a causal sub-tile whose last query precedes this key tile sees none of it (wave-uniform skip);
       // it also guarantees every processed tile starts at a key visible to all 16 queries (finite row maxima)
       if (p.causal && kbase > q0 + 16 * u + 15) continue;
       f32x4 sc[NSUB];
+      if constexpr (STREAM) {
+        // K streamed in two halves of the head dim; the score accumulators carry across
+        f32x4 a[NSUB], al[NSUB];
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) { a[s] = f32x4{0.f, 0.f, 0.f, 0.f}; al[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int kh = 0; kh < NKS / KSH; ++kh) {
+          if (kh) load_k(kh * KSH);
+#pragma unroll
+          for (int s = 0; s < NSUB; ++s)
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks) {
+              mma16<E>(a[s], kcur[s][ks][0], qf[u][kh * KSH + ks][0]);
+              mma16<E>(al[s], kcur[s][ks][0], qf[u][kh * KSH + ks][1]);
+              mma16<E>(al[s], kcur[s][ks][1], qf[u][kh * KSH + ks][0]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NSUB; ++s) sc[s] = a[s] + al[s] * (1.f / SCL);
+        load_v(0, NCH, 0);             // first half of V^T: its latency overlaps the softmax arithmetic
+      } else {
 #pragma unroll
       for (int s = 0; s < NSUB; ++s) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -153,12 +189,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
         }
         sc[s] = a;
       }
-      if constexpr (NP == 2 && QS == 1) {
-#pragma unroll
-        for (int c = NC_EARLY; c < NC; ++c)
-#pragma unroll
-          for (int pl = 0; pl < NP; ++pl) vf[c][pl] = *(const u32x4*)(Vp + pl * kv_lo + (size_t)(kt * NC + c) * (64 * EPC));
       }
+      if constexpr (NP == 2 && QS == 1 && !STREAM) load_v(NC_EARLY, NC, 0);
       // scores -> scaled, biased, masked.  This lane holds keys kbase + goff + j with j = 4s + r (j < 8), so with
       // D = qi - (kbase + goff):  floor((qi - kj) / period) = floor(D / period) - (j > D mod period)   (period >= 8)
       // -> one compare/select/fma per score instead of an int->float convert, floor and two multiplies.
@@ -237,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
           pf = __builtin_bit_cast(u32x4, sc[0]);
         }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) Mma<T>::run(o[u][c], vf[c][0], pf);
+        for (int c = 0; c < NC; ++c) Mma<T>::run(o[u][c], vf[c][0], pf);      // (NCH == NC for the one-plane kinds)
       } else {
         typedef __attribute__((ext_vector_type(8))) E e8;
         e8 ph, plo;
@@ -250,10 +282,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const fdm_attn_args p) {
         }
         const u32x4 pfh = __builtin_bit_cast(u32x4, ph), pfl = __builtin_bit_cast(u32x4, plo);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          mma16<E>(o[u][c], vf[c][0], pfh);
-          mma16<E>(ol[u][c], vf[c][0], pfl);
-          mma16<E>(ol[u][c], vf[c][1], pfh);
+        for (int ch = 0; ch < NC / NCH; ++ch) {
+          if (ch) load_v(0, NCH, ch * NCH);       // (streamed form: second half of the output rows)
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            mma16<E>(o[u][ch * NCH + c], vf[c][0], pfh);
+            mma16<E>(ol[u][ch * NCH + c], vf[c][0], pfl);
+            mma16<E>(ol[u][ch * NCH + c], vf[c][1], pfh);
+          }
         }
       }
     }
@@ -326,8 +362,9 @@ static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
 
 template <typename T>
 static hipError_t attn_launch_dtype(const fdm_attn_args& a, hipStream_t s) {
-  if constexpr (Opnd<T>::NP == 2) {       // split kind: head_dim 64 / 128 (256 does not fit the register file at two waves per SIMD)
-    if (a.hd == 128) attn_launch_t<T, 128>(a, s);
+  if constexpr (Opnd<T>::NP == 2) {       // split kind: head_dim 64 / 128 hold a key tile's fragments, 256 streams them (one wave per SIMD)
+    if (a.hd == 256) attn_launch_t<T, 256>(a, s);
+    else if (a.hd == 128) attn_launch_t<T, 128>(a, s);
     else if (a.hd == 64) attn_launch_t<T, 64>(a, s);
     else return hipErrorInvalidValue;
   } else {

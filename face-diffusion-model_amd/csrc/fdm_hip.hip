@@ -146,7 +146,6 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream) {
   if (a->dtype != FDM_F32 && a->dtype != FDM_BF16 && a->dtype != FDM_F16X3) return fail(FDM_ERR_ARG, "attention: bad dtype %d (FDM_F32, FDM_BF16, FDM_F16X3)", a->dtype);
   if (a->o_split && (a->dtype != FDM_F32 || (a->o_split != FDM_F16X3 && a->o_split != FDM_BF16X3) || a->o_lo_off <= 0))
     return fail(FDM_ERR_ARG, "attention: o_split needs dtype FDM_F32, a split kind and o_lo_off");
-  if (a->dtype == FDM_F16X3 && a->hd == 256) return fail(FDM_ERR_SHAPE, "attention: the split kind supports head_dim 64 and 128");
   if (a->dtype == FDM_F16X3 && (a->q_lo_off <= 0 || a->kv_lo_off <= 0 || a->o_lo_off <= 0 || a->q_lo_off % 8 || a->kv_lo_off % 8 || a->o_lo_off % 4))
     return fail(FDM_ERR_ARG, "attention: split operands need q_lo_off, kv_lo_off and o_lo_off");
   const int epc = a->dtype == FDM_F32 ? 4 : 8;

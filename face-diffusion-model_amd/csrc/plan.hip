@@ -520,7 +520,11 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   FCK(dalloc(P, &P->q, R * d * ea, true));
   FCK(dalloc(P, &P->kp, (size_t)B * repc * Lpad * d * ea, true));
   FCK(dalloc(P, &P->vp, (size_t)B * repc * Lpad * d * ea, true));
-  if (P->dtype == FDM_F16X3 && P->hd == 256) FCK(dalloc_t(P, &P->qkv32, R * 3 * d, true));
+  // (round 2 ran head_dim 256 in FDM_F16X3 through fp32 Q | K | V rows + fdm_op_pack_kv + the fp32 attention kernel: qkv32; the
+  //  split attention kernel now streams K / V at that head_dim, FDM_ATTN_HD256_F32=1 brings the old path back for A/B runs)
+  P->qkv32 = nullptr;
+  if (P->dtype == FDM_F16X3 && P->hd == 256 && getenv("FDM_ATTN_HD256_F32") && !strcmp(getenv("FDM_ATTN_HD256_F32"), "1"))
+    FCK(dalloc_t(P, &P->qkv32, R * 3 * d, true));
   P->q_lo = (long long)(R * d);
   P->kv_lo = (long long)((size_t)B * repc * Lpad * d);
   P->kv_bytes = (size_t)B * repc * Lpad * d * ea;
@@ -576,9 +580,10 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
       g = gemm_op(P, P->x2t, f->w, R, 3 * d, d);
       g.bias = f->bias; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.ln_colsum = f->colsum;
     }
-    // FDM_F16X3: split attention on plane pairs (head_dim 64 / 128).  At head_dim 256 (BIWI) the split kernel's fragments do
-    // not fit the register file: the projection writes fp32 rows, fdm_op_pack_kv lays K / V out for the fp32 attention
-    // kernel (one launch more per layer), whose output returns as a plane pair.  FDM_BF16X3 (comparison mode): fp32 attention.
+    // FDM_F16X3: split attention on plane pairs (head_dim 64 / 128 hold a key tile's fragments in registers, 256 -- BIWI --
+    // streams them at one wave per SIMD).  kv32 (FDM_ATTN_HD256_F32=1, round 2's path, kept for A/B): the projection writes
+    // fp32 rows, fdm_op_pack_kv lays K / V out for the fp32 attention kernel (one launch more per layer), whose output returns
+    // as a plane pair.  FDM_BF16X3 (comparison mode): fp32 attention.
     const bool kv32 = P->qkv32 != nullptr;
     const bool split_attn = P->dtype == FDM_F16X3 && !kv32;
     if (kv32) { g.out_f32 = P->qkv32; g.ldo_f32 = 3 * d; }

@@ -14,7 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from fdm_amd._lib import F16X3, F32  # noqa: E402
+from fdm_amd._lib import BF16, F16X3, F32  # noqa: E402
 from fdm_amd.denoiser import DenoiserPlan  # noqa: E402
 from oracle import fdm_oracle as FO  # noqa: E402
 from oracle import weights as W  # noqa: E402
@@ -84,19 +84,27 @@ def test_cfg4_biwi_full_ddim_chain(dtype):
     assert torch.equal(plan.sample_ddim(xT[1:2], steps)[0], a[1]), "clip result depends on the batch it was sampled in"
 
 
-def test_cfg5_vocaset_end_to_end_composed():
+# cfg5 in every arithmetic mode bench.py offers for it.  (denoiser mode, once-per-clip stages' mode, bar on the first 5 steps of
+# the chain vs the oracle fed the SAME HIP audio features).  The bf16 bar is 2x the measured distance (1.5e-4 over these 5 steps at t = 999..995, whose update coefficients are tiny; round 3);
+# the parity modes state the contract's 1e-4.  f16x3 runs HuBERT / quant / decode in fp32 (bench.py does the same).
+CFG5_MODES = {"f32": (F32, F32, TOL), "bf16": (BF16, BF16, 3e-4), "f16x3": (F16X3, F32, TOL)}
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16x3"])
+def test_cfg5_vocaset_end_to_end_composed(mode):
     from fdm_amd.hubert import HubertPlan
     from fdm_amd.vq import VQPlan
+    dt, side_dt, bar = CFG5_MODES[mode]
     preset, B, T = "vocaset", 4, 1000
     w = W.make_fdm_weights(preset)
     wav = (torch.randn(B, 160000, generator=torch.Generator().manual_seed(100)) * 0.1).to(DEV)
-    hub_plan = HubertPlan(W.make_hubert_weights(24), 24, F32, DEV)
-    vq_plan = VQPlan(preset, W.make_vq_weights(preset), F32, DEV)
+    hub_plan = HubertPlan(W.make_hubert_weights(24), 24, side_dt, DEV)
+    vq_plan = VQPlan(preset, W.make_vq_weights(preset), side_dt, DEV)
     hub = hub_plan.forward(wav)
     assert hub.shape == (B, 498, 1024) and torch.isfinite(hub).all()
     L = 498
     inp = W.synth_inputs(preset, B, L, seed=1)
-    plan = DenoiserPlan(preset, w, F32, DEV)
+    plan = DenoiserPlan(preset, w, dt, DEV)
     plan.prepare(hub, inp["style"], L=L)
     xT = inp["x"].to(DEV)
     ts = list(range(T - 1, -1, -1))
@@ -106,11 +114,14 @@ def test_cfg5_vocaset_end_to_end_composed():
     rec = []
     plan.sample_ddpm(xT, ts[:k], noise=noise, record=rec)
     hub_c = hub.cpu()
+    worst = 0.0
     for b in (0, 3):
         den = lambda x, t: FO.fdm_forward(w, preset, hub_c[b:b + 1], t, x, inp["style"][b:b + 1], None, folded=True)
         ref = []
         FO.p_sample_loop(den, inp["x"][b:b + 1].clone(), noise[:, b:b + 1], ts[:k], record=ref)
-        assert mad(torch.stack(rec)[:, b:b + 1], torch.stack(ref)) < TOL, b
+        worst = max(worst, mad(torch.stack(rec)[:, b:b + 1], torch.stack(ref)))
+    print(f"[cfg5 {mode}] first {k} steps vs oracle: max-abs {worst:.3e} (bar {bar:.1e})")
+    assert worst < bar, mode
 
     def run(clips, clip0):
         plan.prepare(hub[clips], inp["style"][clips], L=L)

@@ -50,7 +50,7 @@ def test_hubert_bf16_stated_tolerance(golden):
     g = golden("hubert")
     p24 = HubertPlan(W.make_hubert_weights(24), 24, BF16, DEV)
     out = p24.forward(wav_for(2, 32000))
-    assert mad(out[0], g["out_L24_2s"]) < 0.15   # 24 bf16 layers on O(4) activations
+    assert mad(out[0], g["out_L24_2s"]) < 0.054  # 24 bf16 layers on O(4) activations: 2x the measured 2.69e-2 (tools/measure_bf16_bars.py, round 3)
 
 
 def vq_case(preset, L, e):
@@ -186,7 +186,7 @@ def test_vq_decode_batch_uses_pe0_for_every_clip_and_bf16():
     out = vq_plan("vocaset").decode(zq.to(DEV))
     assert mad(out, ref) < 1e-4
     outb = vq_plan("vocaset", BF16).decode(zq.to(DEV))
-    assert mad(outb, ref) < 0.5          # decoder outputs are O(12); bf16 operands
+    assert mad(outb, ref) < 0.145        # decoder outputs are O(12); bf16 operands: 2x the measured 7.2e-2 (tools/measure_bf16_bars.py)
 
 
 def test_wav2vec2_base_vs_golden(golden):
@@ -204,7 +204,7 @@ def test_wav2vec2_base_vs_golden(golden):
     assert o.shape == (2, 98, 768) and mad(o[0], g["out_L12_2s"]) < 1e-4
     assert mad(p12.forward(wv(10, 160000))[0, ::8], g["out_L12_10s_rows8"]) < 1e-4
     pb = HubertPlan(W.make_wav2vec_weights(12), 12, BF16, DEV, cfg=WAV2VEC2_BASE)
-    assert mad(pb.forward(wv(2, 32000))[0], g["out_L12_2s"]) < 0.15
+    assert mad(pb.forward(wv(2, 32000))[0], g["out_L12_2s"]) < 0.073      # 2x the measured 3.6e-2 on O(3.5) outputs
 
 
 @pytest.mark.parametrize("preset", ["vocaset", "mead", "biwi"])

@@ -216,11 +216,13 @@ def test_attention_via_qkv_gemm_layout(dtype, B, H, L, hd, causal, period):
 
 
 @pytest.mark.parametrize("B,H,L,hd,causal,period", [(2, 8, 200, 128, True, 30), (1, 4, 37, 128, True, 25), (2, 3, 45, 64, False, 1),
-                                                    (1, 2, 600, 128, True, 30), (3, 2, 8, 128, True, 30)])
+                                                    (1, 2, 600, 128, True, 30), (3, 2, 8, 128, True, 30),
+                                                    (2, 4, 200, 256, True, 25), (1, 2, 75, 256, True, 25), (1, 1, 600, 256, False, 1)])
 def test_split_attention_via_qkv_gemm(B, H, L, hd, causal, period):
     """FDM_F16X3: the QKV GEMM writes Q and the packed K / V as fp16 plane pairs, the split attention kernel runs both
     products in three 16-bit MFMA passes (probabilities split in registers) and writes O as a plane pair.  Checked against an
-    fp64 evaluation of the same fp32 inputs at the fp32 kernel's own tolerance."""
+    fp64 evaluation of the same fp32 inputs at the fp32 kernel's own tolerance.  head_dim 256 (BIWI) streams K and V through
+    the products at one wave per SIMD (attention.hpp, attn_streamed)."""
     g = torch.Generator().manual_seed(L + hd)
     d = H * hd
     x = torch.randn(B * L, d, generator=g)
@@ -234,7 +236,7 @@ def test_split_attention_via_qkv_gemm(B, H, L, hd, causal, period):
     ops.gemm(xs, ws, B * L, 3 * d, d, bias=bqkv.to(DEV), out_t=q, ldo_t=d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d,
              kv_L=L, kv_Lpad=Lpad, kv_hd=hd)
     slopes = torch.tensor([2.0 ** (-(i + 1)) for i in range(H)])
-    scale = 1.0 / math.sqrt(hd) if causal else 0.125
+    scale = 1.0 / math.sqrt(hd) if causal else (0.125 if hd == 64 else 1.0 / math.sqrt(hd))
     o = ops.Split.empty(B * L, d, F16X3, DEV)
     ops.attention(q, kp, vp, o, B=B, H=H, L=L, hd=hd, ldq=d, ldo=d, Lpad=Lpad, scale=scale, causal=causal,
                   slopes=slopes.to(DEV) if causal else None, period=period)
