@@ -470,9 +470,29 @@ class GaussianDiffusion(nn.Module):
         return plan.sample_ddim(x_T.float().contiguous(), steps, cfg_scale=scale)
 
     def forward(self, x, audio, *cond):
-        """Forward-only loss (:757-761); there is no backward pass on this path (training is out of scope)."""
-        t = torch.randint(0, self.num_timesteps, (1,), device=x.device).long().expand(x.shape[0])
-        return self.p_losses(x, t, audio, *cond)
+        """Forward-only loss (:757-761); there is no backward pass on this path (training is out of scope).  Like the reference,
+        one timestep per clip: t = randint(0, T, (b,)) (:759).  The step program shares t across its rows, so clips with
+        different t run as separate B = 1 calls (the reference itself can only run B = 1); equal-sized clips make the mean of
+        the per-clip losses the batch loss."""
+        b = x.shape[0]
+        t = torch.randint(0, self.num_timesteps, (b,), device=x.device).long()
+        if b == 1 or bool((t == t[0]).all()):
+            return self.p_losses(x, t, audio, *cond)
+        m = self.denoise_fn.model if isinstance(self.denoise_fn, ClassifierFreeSampleModel) else self.denoise_fn
+        inj = m._hub if m._hub_key == "injected" else None          # precomputed audio features [B, N, fw]: one clip at a time too
+        losses, recons = [], []
+        try:
+            for i in range(b):
+                if inj is not None:
+                    m.set_audio_features(inj[i:i + 1])
+                ci = tuple(c[i:i + 1] if (torch.is_tensor(c) and c.dim() > 1 and c.shape[0] == b) else c for c in cond)
+                li, ri = self.p_losses(x[i:i + 1], t[i:i + 1], audio[i:i + 1], *ci)
+                losses.append(li)
+                recons.append(ri)
+        finally:
+            if inj is not None:
+                m.set_audio_features(inj)
+        return torch.stack(losses).mean(), torch.cat(recons)
 
 
 # --------------------------------------------------------------------------------------------------

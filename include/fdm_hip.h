@@ -355,8 +355,8 @@ int fdm_plan_commit(fdm_plan* p, void* stream);
 int fdm_audio_prepare(fdm_plan* p, const float* hub, int B, int N, int fw, const float* style, const float* emo,
                       int L, int cfg, void* stream);
 /* The same for S conditions per clip: the reference's sampler loops the style one-hots of a clip through ddim_sample one
- * B = 1 call at a time with the SAME audio (samples/sample_diffusion_vocaset.py:71-83; MEAD: emotion x identity,
- * samples/sample_diffusion_mead.py:67-86).  Here the S conditions of each of the B clips run as B*S rows blocks of ONE step
+ * B = 1 call at a time with the SAME audio (samples/sample_diffusion_vocaset.py:71-83; for 3D-MEAD any set of
+ * (emotion, identity) pairs of one utterance).  Here the S conditions of each of the B clips run as B*S rows blocks of ONE step
  * program: row block (b, s) = "virtual clip" b*S + s.  style [B*S, n_style], emo [B*S, n_emo] or NULL (virtual-clip order);
  * AF and the C1_l tables are computed once per CLIP (B*L rows) and shared by its S conditions -- only E0 is per condition.
  * Afterwards the plan's batch is B*S clips: x_T / out / noise of fdm_sample_graph and fdm_denoise_step are

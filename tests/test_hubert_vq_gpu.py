@@ -247,6 +247,37 @@ def test_q_sample_and_forward_loss():
     assert abs(float(loss) - float(torch.nn.functional.mse_loss(inp["x"], ref))) < 1e-5
 
 
+def test_forward_loss_draws_one_timestep_per_clip():
+    """GaussianDiffusion.forward: t = randint(0, T, (b,)) like the reference (diffusion_BIWI_encoder_decoder.py:757-761); clips
+    with different t run as B = 1 calls, the batch loss is the mean of the per-clip losses."""
+    from fdm_amd.modules import FDM, GaussianDiffusion
+    from oracle import fdm_oracle as FO
+    model = FDM(feature_dim=1024, audio_encoder=False)
+    w = W.make_fdm_weights("vocaset")
+    model.load_state_dict(w, strict=False)
+    diff = GaussianDiffusion(model, timesteps=1000, loss_type="l2").to(DEV)
+    B, L = 3, 9
+    inp = W.synth_inputs("vocaset", B, L, seed=13)
+    model.set_audio_features(inp["hub"].to(DEV))
+    x0 = inp["x"].to(DEV)
+    torch.manual_seed(5)                     # replay forward's draws: t for the batch, then one noise tensor per clip
+    t = torch.randint(0, 1000, (B,), device=DEV).long()
+    zs = [torch.randn_like(x0[i:i + 1]) for i in range(B)]
+    assert len(set(t.tolist())) > 1
+    torch.manual_seed(5)
+    loss, x_recon = diff(x0, torch.zeros(B, 16, device=DEV), inp["style"].to(DEV))
+    buf = FO.schedule_buffers()
+    per_clip = []
+    for i in range(B):
+        ti = int(t[i])
+        xn = buf["sqrt_alphas_cumprod"][ti] * inp["x"][i:i + 1] + buf["sqrt_one_minus_alphas_cumprod"][ti] * zs[i].cpu()
+        ref = FO.fdm_forward(w, "vocaset", inp["hub"][i:i + 1], ti, xn, inp["style"][i:i + 1], None, folded=True)
+        assert mad(x_recon[i:i + 1], ref) < 1e-4, i
+        per_clip.append(float(torch.nn.functional.mse_loss(inp["x"][i:i + 1], ref)))
+    assert abs(float(loss) - sum(per_clip) / B) < 1e-5
+    assert model._hub.shape[0] == B, "the injected features must be restored after the per-clip loop"
+
+
 def test_hubert_torch20_weight_norm_names_and_hf_prefixes():
     """A torch-2.0 / HF *ForCTC checkpoint spells the positional conv's weight-norm tensors weight_g / weight_v and prefixes
     every key with `hubert.`: both load and give the same features bit for bit."""
