@@ -328,11 +328,24 @@ def main():
     if rank == 0:
         # Counter-derived fields (HBM-side bytes per launch of the step graph, MFMA-busy share, the dominant kernel's own
         # roofline entry) come from the committed rocprofv3 --pmc summary of THIS configuration and mode (bench.py cannot
-        # collect PMC counters on itself).  They are refused (null) when the summary was taken on another step program:
-        # its kernel-launch count per diffusion step and its GEMM tile set must equal the running build's.
+        # collect PMC counters on itself).  They are refused (null) when the summary was taken on another step program (its
+        # kernel-launch count per diffusion step must equal the running build's); the tile set the summary was profiled with is
+        # reported next to this run's (`counters_tiles`, `counters_tiles_match`), and the dominant kernel's entry is dropped when
+        # this run's tiles at ITS call sites (out-proj, FFN2) differ from the profiled ones -- nothing is paired silently.
+        def parse_tiles(txt):
+            out = {}
+            for part in str(txt or "").split(","):
+                if "=" in part:
+                    k, v = part.split("=", 1)
+                    try:
+                        out[k.strip()] = int(v)
+                    except ValueError:
+                        pass
+            return out
+
         def counters(leg):
             r = leg["roofline"]
-            r.update({"mfma_busy": None, "dominant_kernel": None, "counters_from": None})
+            r.update({"mfma_busy": None, "dominant_kernel": None, "counters_from": None, "counters_tiles": None, "counters_tiles_match": None})
             if a.batch:
                 return
             for rd in ("r3", "r2"):
@@ -341,11 +354,15 @@ def main():
                     pm = json.load(open(os.path.join(ROOT, rel)))
                     if int(round(pm["summary"]["launches_per_step"])) != int(leg["kernel_launches_per_diffusion_step"]):
                         continue
+                    prof_tiles = {k: v for k, v in parse_tiles(pm["summary"].get("tiles")).items() if v}
                     r["traffic"] = pm["summary"]["traffic_bytes_per_step"]
                     r["mfma_busy"] = pm["summary"]["mfma_busy_time_weighted"]
                     r["counters_from"] = rel
+                    r["counters_tiles"] = prof_tiles
+                    r["counters_tiles_match"] = prof_tiles == leg["gemm_tiles"]
                     ks = [k for k in pm["kernels"] if "gemm" in k["kernel"]]
-                    if ks:
+                    same_sites = all(prof_tiles.get(site, 0) == leg["gemm_tiles"].get(site, 0) for site in ("out", "ffn2"))
+                    if ks and same_sites:
                         k = max(ks, key=lambda q: q["launches_per_step"] * q["avg_us"])
                         r["dominant_kernel"] = {"name": k["kernel"], "launches_per_step": k["launches_per_step"], "avg_us_profiled": k["avg_us"],
                                                 "mfma_busy": k.get("mfma_busy"), "wave_cycles_waiting": k.get("wait"), "l2_hit": k.get("l2_hit"),

@@ -718,30 +718,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
         for (int ni = 0; ni < NI; ++ni) wf[s][ni][pl] = *(const u32x4*)(base + pl * BN * ROWB + (w_off[ni] ^ (s << 6)));
       }
   };
-#ifdef FDM_PP_MFMA32
-  // timing experiment only (results are garbage): the same registers fed to 32x32x16 MFMAs -- half the A/B operand fetches per flop
-  typedef __attribute__((ext_vector_type(16))) float f32x16;
-  f32x16 acc32[MI / 2][NI / 2];
-#pragma unroll
-  for (int a_ = 0; a_ < MI / 2; ++a_)
-#pragma unroll
-    for (int b_ = 0; b_ < NI / 2; ++b_)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc32[a_][b_][j] = 0.f;
-#endif
   auto compute = [&]() {
-#ifdef FDM_PP_MFMA32
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-        for (int a_ = 0; a_ < MI / 2; ++a_)
-#pragma unroll
-          for (int b_ = 0; b_ < NI / 2; ++b_)
-            acc32[a_][b_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[s][2 * b_ + hh][0]), __builtin_bit_cast(bf16x8, af[s][2 * a_ + hh][0]), acc32[a_][b_], 0, 0, 0);
-    return;
-#endif
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -814,14 +791,6 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
   if (!grp) __builtin_amdgcn_s_barrier();           // matches group 1's late start
 #ifdef FDM_PP_PHASES
   if (phases) phases[2] = wall_clock64();
-#endif
-#ifdef FDM_PP_MFMA32
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[mi][ni][j] = acc32[mi / 2][ni / 2][(mi & 1) * 8 + (ni & 1) * 4 + j];
 #endif
   if constexpr (NP == 2) {
     constexpr float inv = 1.f / Opnd<T>::SCALE;

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <algorithm>
 #include <vector>
 
@@ -62,6 +63,22 @@ int main(int argc, char** argv) {
 #endif
   for (int i = 0; i < 8; ++i) run(i);
   CK(hipStreamSynchronize(s));
+#if FDM_PP_VARIANT == 0 && !defined(FDM_PP_MFMA32)
+  {   // spot check of the last launch (weights W[7]) against a host dot product of the same bf16 operands
+    auto bf = [](unsigned short v) { unsigned int u = (unsigned int)v << 16; float f; memcpy(&f, &u, 4); return (double)f; };
+    std::vector<float> ho((size_t)M * N);
+    CK(hipMemcpy(ho.data(), out, ho.size() * 4, hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    for (int t = 0; t < 256; ++t) {
+      const int m = (int)(((long long)t * 7919 + 13) % M), n = (int)(((long long)t * 104729 + 7) % N);
+      double r = 0.0;
+      for (int k = 0; k < K; ++k) r += bf(h[(size_t)m * K + k]) * bf(h[7 * 64 + (size_t)n * K + k]);
+      const double e = fabs(r - (double)ho[(size_t)m * N + n]) / (fabs(r) + 1e-3);
+      if (e > worst) worst = e;
+    }
+    printf("spot check (256 outputs vs host fp64): worst relative error %.2e %s\n", worst, worst < 2e-3 ? "ok" : "MISMATCH");
+  }
+#endif
 #ifdef FDM_PP_STAMPS
   {
     std::vector<unsigned long long> hs(8 * 64);
