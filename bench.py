@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--contract-steps", type=int, default=5, help="timed sampling calls of the contract-mode (f16x3) leg")
     ap.add_argument("--profile-steps", type=int, default=0, help="profiling only: shorten the diffusion chain to this many steps")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU instead of the configuration's (row-count sweeps, tests)")
+    ap.add_argument("--broadcast-weights", action="store_true",
+                    help="N > 1: rank 0's weights are broadcast to every rank (one flattened RCCL broadcast, outside the timed region) "
+                         "instead of each rank generating its own copy from the seed")
     ap.add_argument("--dump", default="", help="tests only: rank 0 saves the gathered output of the last call to this .npy file")
     a = ap.parse_args()
 
@@ -192,7 +195,10 @@ def main():
     if a.batch:
         B = a.batch
     p = presets.get(preset)
-    weights = W.make_fdm_weights(preset)
+    weights = W.make_fdm_weights(preset, seed=0 if (rank == 0 or not a.broadcast_weights) else 12345)
+    if a.broadcast_weights and dist is not None:      # ranks > 0 start from a DIFFERENT seed: equal results prove the broadcast
+        from fdm_amd.parallel import broadcast_state
+        broadcast_state(weights, dist, src=0, device=dev if dist.get_backend() == "nccl" else None)
     inp = W.synth_inputs(preset, B * world, L, seed=1)      # global batch; this rank owns clips [rank*B, (rank+1)*B)
     sl = slice(rank * B, (rank + 1) * B)
     emo = inp["emo"][sl] if "emo" in inp else None
@@ -383,6 +389,7 @@ def main():
                                       if e2e else "synthetic audio-encoder features, Philox noise"), "global_batch": B * world,
                        "latent_frames": L, "diffusion_steps": T, "parallelism": f"clip-shard x{world}"},
             "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
+            "weights": ("broadcast from rank 0 (one flattened collective)" if (a.broadcast_weights and dist is not None) else "generated per rank from the seed"),
             "dist_backend": (dist.get_backend() if dist is not None else None),
             "diffusion_steps_per_s": head["diffusion_steps_per_s"],
             "kernel_launches_per_diffusion_step": head["kernel_launches_per_diffusion_step"],

@@ -901,9 +901,13 @@ template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   const long long batch = a.batch > 0 ? a.batch : 1;
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
-  if (a.sched_fuse)       // (validated: interior tiles only -> the lean epilogue)
+  if (a.sched_fuse) {     // (validated: interior tiles only -> the lean epilogue)
+    // thousands of rows: the scheduler-fused latent decoder on the ping-pong tile when the plan's tuner picked it
+    if (a.tile == FDM_TILE_256x128_PP && !a.ln_stat_in && a.N % 128 == 0)
+      return gemm_pp_launch_h<T, 256, 128, 4, 2, 3, false, true, GEMM_LEAN>(a, s);
     return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
                         : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
+  }
   switch (a.tile > 0 ? a.tile : gemm_tile_override()) {
     case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);      // 8 waves, 32x16 per wave
     case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave

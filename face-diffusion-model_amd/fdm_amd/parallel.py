@@ -3,8 +3,9 @@
 Clips are fully independent (attention is per clip, LayerNorm per token, InstanceNorm per clip-channel;
 the reference processes one clip at a time, samples/sample_diffusion_vocaset.py:51), so there is no
 exchange step inside the T-step loop.  One process per GPU; rank r owns clips [r*B/W, (r+1)*B/W); every
-rank holds the full weights; the only collective on the path is one all-gather of the finished outputs
-(RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests).  Per-clip noise streams are keyed by
+rank holds the full weights (optionally broadcast once from rank 0 as one flattened arena: broadcast_state); the only
+collective on the path is one all-gather of the finished outputs (RCCL over xGMI when the backend is "nccl"; gloo in the
+CPU tests).  Per-clip noise streams are keyed by
 the global clip index, so results are bit-identical for any world size."""
 import torch
 
@@ -40,10 +41,23 @@ def gather_clips(local, dist=None, sizes=None):
     return torch.cat([o[:s] for o, s in zip(out, sizes)])
 
 
-def broadcast_state(state, dist=None, src=0):
-    """Optional init-time broadcast of a state dict (weights / conditioning) from rank `src`."""
+def broadcast_state(state, dist=None, src=0, device=None):
+    """Init-time broadcast of a state dict (weights / conditioning) from rank `src`: ONE collective per dtype over a
+    flattened arena (xGMI links are point to point: few large transfers, not hundreds of small ones), unflattened in place.
+    Every rank passes tensors of the same names / shapes (e.g. freshly constructed modules); rank `src`'s values win.
+    device: where the arena lives for the collective (a cuda device for the RCCL backend; None = the tensors' own)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return state
+    by_dtype = {}
     for k in sorted(state):
-        dist.broadcast(state[k], src=src)
+        by_dtype.setdefault(state[k].dtype, []).append(k)
+    for dt, keys in by_dtype.items():
+        dev = device if device is not None else state[keys[0]].device
+        flat = torch.cat([state[k].detach().reshape(-1).to(dev) for k in keys]) if keys else None
+        dist.broadcast(flat, src=src)
+        off = 0
+        for k in keys:
+            n = state[k].numel()
+            state[k].detach().copy_(flat[off:off + n].reshape(state[k].shape).to(state[k].device))
+            off += n
     return state

@@ -89,7 +89,7 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    FDM_DIST_BACKEND="gloo")
-        procs.append(subprocess.Popen(common + ["--gpus", "2", "--batch", "1", "--dump", two], env=env, stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen(common + ["--gpus", "2", "--batch", "1", "--dump", two, "--broadcast-weights"], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=900) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[0] + o[1] for o in outs)
@@ -98,6 +98,7 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 2
     assert rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo"        # self-checking: the line says how many ranks really ran
+    assert rec["weights"].startswith("broadcast")        # rank 1 started from another seed: bit-equal outputs below prove the broadcast
     assert rec["parity"]["max_abs"] < 1e-4 and rec["parity"]["dtype"] == "f32"
     a, b = np.load(one), np.load(two)
     assert a.shape == b.shape == (2, 1600, 64) and np.array_equal(a, b)

@@ -84,6 +84,29 @@ def test_gemm_split_operands(dtype, tol, M, N, K, act, tile):
         assert torch.equal(o2, o32)
 
 
+@pytest.mark.parametrize("dtype", [BF16, F32])
+def test_pingpong_tile_is_bit_identical_and_race_free(dtype):
+    """FDM_TILE_256x128_PP (two wave groups half a period apart, counted vmcnt across raw barriers): the same bits as the 64x64
+    tile on interior and edge shapes -- one k-tile (prologue == tail), two, odd row counts, N not a tile multiple (general
+    epilogue), K up to 4096 -- and over 10 repeated launches each (a landing or reuse race shows as a run-to-run difference)."""
+    from fdm_amd._lib import TILE_256x128_PP, TILE_64x64
+    g = torch.Generator().manual_seed(77)
+    k_unit = 64 if dtype == BF16 else 32
+    shapes = [(256, 128, k_unit), (300, 256, 2 * k_unit), (515, 384, 3 * k_unit), (1000, 200, 5 * k_unit), (2049, 1024, 1024), (6400, 1024, 2048),
+              (777, 3072, 1024), (4096, 512, 4096)]
+    for (M, N, K) in shapes:
+        A = ops.to_operand(torch.randn(M, K, generator=g).to(DEV), dtype)
+        W = ops.to_operand((torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV), dtype)
+        bias = torch.randn(N, generator=g).to(DEV)
+        res = torch.randn(M, N, generator=g).to(DEV)
+        ref = torch.zeros(M, N, device=DEV)
+        ops.gemm(A, W, M, N, K, bias=bias, act=ACT_RELU, resid=res, out_f32=ref, tile=TILE_64x64)
+        for rep in range(10):
+            out = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(A, W, M, N, K, bias=bias, act=ACT_RELU, resid=res, out_f32=out, tile=TILE_256x128_PP)
+            assert torch.equal(out, ref), f"dtype {dtype} shape {(M, N, K)} rep {rep}: max diff {float((out - ref).abs().max())}"
+
+
 def test_split_producers_write_plane_pairs():
     """LayerNorm, scheduler and fp32 attention write GEMM inputs as plane pairs in the split modes."""
     g = torch.Generator().manual_seed(3)

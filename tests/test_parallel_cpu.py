@@ -38,9 +38,10 @@ def _worker(rank, world, port, n_clips, q):
         full = gather_clips(local, dist)
         ref = torch.stack([_fake_clip_result(i) for i in range(n_clips)])
         ok = torch.equal(full, ref)
-        state = {"w": torch.full((4,), float(rank + 1)), "b": torch.arange(3.0) * (rank + 1)}
+        state = {"w": torch.full((4, 2), float(rank + 1)), "b": torch.arange(3.0) * (rank + 1), "idx": torch.arange(5) + 10 * rank}
         broadcast_state(state, dist, src=0)
-        ok = ok and torch.equal(state["w"], torch.ones(4)) and torch.equal(state["b"], torch.arange(3.0))
+        ok = ok and torch.equal(state["w"], torch.ones(4, 2)) and torch.equal(state["b"], torch.arange(3.0))
+        ok = ok and torch.equal(state["idx"], torch.arange(5))             # one flattened collective per dtype
         q.put((rank, lo, hi, bool(ok)))
     finally:
         dist.destroy_process_group()
