@@ -436,3 +436,36 @@ def test_weight_update_rebuilds_tables_without_growing():
         if it > 1:
             assert base - free < (1 << 20), f"device memory grew by {(base - free) >> 10} KiB after weight update {it}"
     assert mad(a, FO.fdm_forward(w, "vocaset_tiny", inp["hub"], 500, inp["x"], inp["style"], None, folded=True)) < TOL32
+
+
+def test_tile_override_applies_at_prepare_and_tuning_is_plan_time(monkeypatch):
+    """FDM_TILE_OVERRIDE pins call sites at fdm_audio_prepare whether or not the tuner runs (a C caller that only
+    calls fdm_sample_graph gets the pinned tiles), and a sampling call never tunes by itself: tuning is fdm_plan_tune, or
+    fdm_audio_prepare for a shape that has already served 2000 steps (or opt-in: fdm_plan_set(p, "tune_lazy", 1))."""
+    w = W.make_fdm_weights("vocaset_tiny")
+    L = 24
+    inp = W.synth_inputs("vocaset_tiny", 2, L, seed=6)
+    monkeypatch.setenv("FDM_TUNE", "0")
+    monkeypatch.setenv("FDM_TILE_OVERRIDE", "out=2,ffn1=6")
+    plan = DenoiserPlan("vocaset_tiny", w, F32, DEV)
+    plan.prepare(inp["hub"], inp["style"], L=L)
+    assert plan.tiles["out"] == 2 and plan.tiles["ffn1"] == 6 and plan.get("tuned") == 0
+    ref = plan.sample_ddim(inp["x"].to(DEV), 20)
+    monkeypatch.delenv("FDM_TILE_OVERRIDE")
+    monkeypatch.delenv("FDM_TUNE")
+    plan2 = DenoiserPlan("vocaset_tiny", w, F32, DEV)
+    plan2.prepare(inp["hub"], inp["style"], L=L)
+    ts = list(range(999, -1, -1))
+    for _ in range(3):                                  # 3000 steps at this shape: still untuned, sampling calls only count
+        out = plan2.sample_ddpm(inp["x"].to(DEV), ts, seed=1)
+        assert plan2.get("tuned") == 0
+    plan2.prepare(inp["hub"], inp["style"], L=L)       # plan time: the shape has served >= 2000 steps -> tuned here
+    assert plan2.get("tuned") == 1
+    assert torch.equal(plan2.sample_ddpm(inp["x"].to(DEV), ts, seed=1), out)        # tiles change speed, never results
+    assert torch.equal(plan2.sample_ddim(inp["x"].to(DEV), 20), ref)
+    plan3 = DenoiserPlan("vocaset_tiny", w, F32, DEV)
+    plan3.set("tune_lazy", 1)
+    plan3.prepare(inp["hub"], inp["style"], L=L)
+    for _ in range(3):
+        plan3.sample_ddpm(inp["x"].to(DEV), ts, seed=1)
+    assert plan3.get("tuned") == 1                      # opted in: the third call (2000 steps seen) tuned in-call

@@ -104,6 +104,44 @@ def test_demo_cli_writes_reference_output_layout(tmp_path):
     assert arr.shape == (1, 98, 15069) and arr.dtype == np.float32 and np.isfinite(arr).all()
 
 
+def test_style_loop_batched_equals_the_reference_loop(tmp_path):
+    """The sampler of samples/sample_diffusion_vocaset.py:59-88 with every style one-hot of a clip: ONE condition-batched call
+    per clip (audio encoder once, audio tables once, 8 conditions in one step program) writes the same files with the same
+    bits as the reference's loop of eight B = 1 calls (audio -> HuBERT -> ddim_sample -> quant -> decode + template)."""
+    import importlib.util
+    import os
+    import sys
+    from fdm_amd import pipeline, presets
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sd = os.path.join(here, "face-diffusion-model_amd", "dropin", "samples")
+    sys.path.insert(0, os.path.dirname(sd))
+    spec = importlib.util.spec_from_file_location("sample_diffusion", os.path.join(sd, "sample_diffusion.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    p = presets.get("vocaset")
+    diffusion, ae = pipeline.build_models("vocaset", None, DEV)
+    enc = diffusion.denoise_fn.audio_encoder
+    calls = {"n": 0}
+    orig = enc.forward
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    enc.forward = counting
+    for mode, batched in (("batched", True), ("sequential", False)):
+        calls["n"] = 0
+        mod.sample_step(mod.synthetic_loader(p, 1, 1.0), DEV, diffusion, ae, str(tmp_path / mode), p, 4, all_styles=True, batched=batched)
+        # batched: the audio encoder runs once per CLIP; the loop encodes once per call (the reference even re-encodes per step)
+        assert calls["n"] == (1 if batched else p.n_style), f"{mode}: the audio encoder ran {calls['n']} times for one clip"
+    for it in range(p.n_style):
+        a = np.load(str(tmp_path / "batched" / f"synthetic_000_condition_{it}.npy"))
+        b = np.load(str(tmp_path / "sequential" / f"synthetic_000_condition_{it}.npy"))
+        assert a.shape == b.shape == (1, 48, 15069) and np.array_equal(a, b), it
+    a0 = np.load(str(tmp_path / "batched" / "synthetic_000_condition_0.npy"))
+    a5 = np.load(str(tmp_path / "batched" / "synthetic_000_condition_5.npy"))
+    assert not np.array_equal(a0, a5)          # the style does change the animation
+
+
 def test_mead_end_to_end_animate_with_evq():
     """3D-MEAD wiring of samples/sample_diffusion_mead.py:67-86: sample(audio, shape, emo, id) -> quant(result, emo)
     -> decode; short chain (t_range) on random-init weights; checks shapes, finiteness, emotion-sliced codebook use
