@@ -295,7 +295,7 @@ def main():
                             "achieved": round(ach, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s",
                             "frac": round(ach / PEAK[dtype_name], 4), "traffic": None,
                             "flops_per_launch": fl, "avg_launch_ms": round(step_ms, 5)}}
-        if S > 1:
+        if S > 1 and not a.profile_steps:
             # the reference's own loop: one B = 1 sampling call per style, same audio (tables rebuilt per call, as a caller that
             # loops ddim_sample does); same plan, same tiles policy, same timing harness
             st1 = [style[i:i + 1] for i in range(B * S)]
