@@ -311,9 +311,12 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   __syncthreads();
   {
     constexpr int TPQ = 256 / BQ;                    // threads per query row (16 or 8)
-    constexpr int EPT = HD / TPQ;                    // consecutive head-dim elements per thread (multiple of 4)
+    constexpr int EPT = HD / TPQ;                    // head-dim elements per thread (multiple of 4)
+    // a thread takes EPT / 4 float4 pieces TPQ * 4 floats apart: the lanes of a read group then sit on consecutive 16-byte
+    // slots (conflict-free for every head dim; the contiguous-run mapping was 2-way conflicted at head dim 256) and a wave's
+    // store covers whole 256-byte runs of an output row
     const int q = threadIdx.x / TPQ;
-    const int e0 = (threadIdx.x % TPQ) * EPT;
+    const int e0 = (threadIdx.x % TPQ) * 4;
     const int qq = q0 + q;
     float mw[4], ms = -INFINITY;
 #pragma unroll
@@ -325,7 +328,8 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
     if (qq < L) {
       const size_t oo = ((size_t)b * L + qq) * p.ldo + (size_t)h * HD + e0;
 #pragma unroll
-      for (int j = 0; j < EPT; j += 4) {
+      for (int jj = 0; jj < EPT / 4; ++jj) {
+        const int j = jj * TPQ * 4;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) v += *(const f32x4*)&part_o[w][q][e0 + j] * sw[w];
