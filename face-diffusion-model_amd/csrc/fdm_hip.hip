@@ -82,7 +82,21 @@ int grid_for(long long n) {
 extern "C" {
 
 const char* fdm_last_error(void) { return g_err.c_str(); }
-int fdm_version(void) { return 100; }
+int fdm_version(void) { return 103; }      // 1.03: round 3 (fdm_audio_prepare_conds, fdm_vq_quant_stats, fdm_ln_args row map)
+
+// sizeof() of a public struct as THIS build sees it: a binding compares it with its own mirror before the first call
+int fdm_abi_struct_size(const char* name) {
+  if (!name) return fdm::fail(FDM_ERR_ARG, "abi_struct_size: null name");
+  const std::string n(name);
+  if (n == "fdm_sched_args") return (int)sizeof(fdm_sched_args);
+  if (n == "fdm_gemm_args") return (int)sizeof(fdm_gemm_args);
+  if (n == "fdm_attn_args") return (int)sizeof(fdm_attn_args);
+  if (n == "fdm_ln_args") return (int)sizeof(fdm_ln_args);
+  if (n == "fdm_model_desc") return (int)sizeof(fdm_model_desc);
+  if (n == "fdm_sample_args") return (int)sizeof(fdm_sample_args);
+  if (n == "fdm_vq_desc") return (int)sizeof(fdm_vq_desc);
+  return fdm::fail(FDM_ERR_ARG, "abi_struct_size: unknown struct '%s'", name);
+}
 
 int fdm_device_ok(void) {
   int n = 0;

@@ -69,10 +69,15 @@ class LnArgs(C.Structure):
                 ("add_mat_L", ci), ("add_mat_group", ci), ("add_mat_wrap", ci)]
 
 
+# public structs of include/fdm_hip.h -> their mirrors (sizes checked against the loaded library in lib())
+STRUCTS = {"fdm_sched_args": SchedArgs, "fdm_gemm_args": GemmArgs, "fdm_attn_args": AttnArgs, "fdm_ln_args": LnArgs,
+           "fdm_model_desc": ModelDesc, "fdm_sample_args": SampleArgs, "fdm_vq_desc": VqDesc}
+
 # every symbol include/fdm_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "fdm_last_error": (C.c_char_p, []),
     "fdm_version": (ci, []),
+    "fdm_abi_struct_size": (ci, [C.c_char_p]),
     "fdm_device_ok": (ci, []),
     "fdm_op_gemm": (ci, [C.POINTER(GemmArgs), vp]),
     "fdm_op_attention": (ci, [C.POINTER(AttnArgs), vp]),
@@ -155,6 +160,13 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        # the ctypes mirrors above must be the structs this build was compiled with (a stale .so or a header edit that
+        # missed this file would otherwise corrupt arguments silently)
+        for cname, mirror in STRUCTS.items():
+            n = l.fdm_abi_struct_size(cname.encode())
+            if n != C.sizeof(mirror):
+                raise FdmError(f"{LIB_PATH}: sizeof({cname}) = {n} in the library, {C.sizeof(mirror)} in fdm_amd/_lib.py: rebuild the "
+                               "library (python -c 'import __graft_entry__ as g; g.build()') or update the binding")
         _lib = l
     return _lib
 

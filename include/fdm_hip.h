@@ -61,6 +61,9 @@ extern "C" {
 
 const char* fdm_last_error(void);
 int fdm_version(void);
+/* sizeof() of a public struct of this header ("fdm_gemm_args", "fdm_ln_args", ...) in the loaded build: lets a binding in
+ * another language check its mirror of the struct before the first call (negative = unknown name) */
+int fdm_abi_struct_size(const char* name);
 /* 1 if a gfx950 device is visible to this process, else 0 (no device is touched otherwise) */
 int fdm_device_ok(void);
 

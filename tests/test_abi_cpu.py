@@ -26,7 +26,11 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(l, n), f"{n} declared in include/fdm_hip.h but not exported"
         assert n in _lib.SYMBOLS, f"{n} has no ctypes binding"
-    assert l.fdm_version() >= 100
+    assert l.fdm_version() >= 103
+    import ctypes as _C
+    for cname, mirror in _lib.STRUCTS.items():          # the ctypes mirrors are the structs the library was built with
+        assert l.fdm_abi_struct_size(cname.encode()) == _C.sizeof(mirror), cname
+    assert l.fdm_abi_struct_size(b"no_such_struct") == -1
 
 
 def test_argument_validation_without_device():
