@@ -47,6 +47,25 @@ def sample_step(loader, dev, diffusion, autoencoder, save_folder, p, ddim_steps,
             print(f"saved {dst}.npy {tuple(out.shape)}")
 
 
+@torch.no_grad()
+def sample_batched(loader, dev, diffusion, autoencoder, save_folder, p, ddim_steps, emotion=4, max_batch=8):
+    """The same files as sample_step (style 0 of every clip), but clips of the loader -- whatever their durations -- go through
+    ONE sampling call per `max_batch` clips (pipeline.animate_many: exact, the denoiser's attention is causal) instead of the
+    reference's one B = 1 call per clip (samples/sample_diffusion_vocaset.py:51: batch size 1)."""
+    os.makedirs(save_folder, exist_ok=True)
+    items = list(loader)
+    audios = [a[0].numpy() for a, _, _, _ in items]
+    tmpl = [t for _, t, _, _ in items]
+    ids = [oh[:, 0, :] for _, _, oh, _ in items]
+    emo = [torch.eye(p.n_emo)[emotion:emotion + 1]] * len(items) if p.n_emo else None
+    verts, _ = pipeline.animate_many(diffusion, autoencoder, audios, tmpl, ids, emo, ddim_steps=None if p.n_emo else ddim_steps,
+                                     device=dev, max_batch=max_batch)
+    for (_, _, _, file_name), out in zip(items, verts):
+        dst = os.path.join(save_folder, f"{file_name[:-4]}_condition_0")
+        np.save(dst, out.detach().cpu().numpy())
+        print(f"saved {dst}.npy {tuple(out.shape)}")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--dataset", default="vocaset", choices=["vocaset", "mead", "biwi"])
@@ -59,8 +78,12 @@ if __name__ == "__main__":
     ap.add_argument("--stage2_model_path", default="")
     ap.add_argument("--all_styles", action="store_true", help="every style one-hot of each clip (the reference's loop), as one batched call")
     ap.add_argument("--sequential", action="store_true", help="with --all_styles: one B = 1 call per style, as the reference does")
+    ap.add_argument("--batch", type=int, default=1, help="clips per sampling call (clips of different durations batch exactly)")
     a = ap.parse_args()
     p = presets.get(a.dataset)
     diffusion, ae = pipeline.build_models(a.dataset, None, a.device, a.stage1_model_path, a.stage2_model_path)
-    sample_step(synthetic_loader(p, a.clips, a.seconds), a.device, diffusion, ae, a.out, p, a.ddim_steps,
-                all_styles=a.all_styles, batched=not a.sequential)
+    if a.batch > 1 and not a.all_styles:
+        sample_batched(synthetic_loader(p, a.clips, a.seconds), a.device, diffusion, ae, a.out, p, a.ddim_steps, max_batch=a.batch)
+    else:
+        sample_step(synthetic_loader(p, a.clips, a.seconds), a.device, diffusion, ae, a.out, p, a.ddim_steps,
+                    all_styles=a.all_styles, batched=not a.sequential)

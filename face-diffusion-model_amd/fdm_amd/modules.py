@@ -442,7 +442,10 @@ class GaussianDiffusion(nn.Module):
         return plan.sample_ddpm(x.float().contiguous(), [tt], noise=z.reshape(1, *x.shape), cfg_scale=scale, use_graph=False)
 
     @torch.no_grad()
-    def p_sample_loop(self, shape, audio, *cond, noise=None, seed=None, t_range=None, guidance_scale=None):
+    def p_sample_loop(self, shape, audio, *cond, noise=None, seed=None, t_range=None, guidance_scale=None, x_T=None, clip0=0):
+        """Build-added keywords (default = reference behaviour): noise=(x_T, z[T]) injects everything (parity runs); x_T= fixes the
+        start with in-kernel Philox noise keyed by (seed, clip0 + row block, step): a clip's result depends on its index, not on
+        the batch it is sampled in."""
         plan, scale = self._plan(audio, shape, cond, guidance_scale)
         dev = plan.device
         if t_range is None:
@@ -451,9 +454,9 @@ class GaussianDiffusion(nn.Module):
         if noise is not None:
             x_T, z = noise[0].to(dev), noise[1]
             return plan.sample_ddpm(x_T.float().contiguous(), ts, noise=z, cfg_scale=scale)
-        x_T = torch.randn((plan.B,) + tuple(shape[1:]), device=dev)      # one row block per (clip, condition)
+        x_T = torch.randn((plan.B,) + tuple(shape[1:]), device=dev) if x_T is None else x_T.to(dev).float().contiguous()
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if seed is None else int(seed)
-        return plan.sample_ddpm(x_T, ts, seed=seed, cfg_scale=scale)
+        return plan.sample_ddpm(x_T, ts, seed=seed, clip0=int(clip0), cfg_scale=scale)
 
     @torch.no_grad()
     def sample(self, audio, latent_motion_shape, *cond, **kw):

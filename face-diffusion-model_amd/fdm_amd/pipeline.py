@@ -117,6 +117,70 @@ def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emoti
     return out, latent
 
 
+@torch.no_grad()
+def animate_many(diffusion, autoencoder, audios, templates=None, id_one_hots=None, emotion_one_hots=None, ddim_steps=None,
+                 seed=0, device="cuda:0", max_batch=8):
+    """A test set's clips (different durations) through ONE sampling call per group of `max_batch` clips.
+
+    The reference's samplers take the clips of a loader one at a time (bs = 1: samples/sample_diffusion_vocaset.py:51,71-83),
+    which is the few-hundred-row regime where this path reaches 1-2 % of the MFMA roofline.  Clips of different lengths batch
+    EXACTLY: the denoiser's self-attention is causal (models/fdm_vocaset.py:85,107-115: key j > query i is masked), every other
+    op is per row, and the in-kernel noise is keyed by (clip, element index inside the clip) -- so a clip padded at its END to
+    the group's longest length computes, for its own frames, bit for bit what its B = 1 call computes; the tail rows are
+    discarded.  The audio encoder and the VQ decoder are not causal: they run per clip at the clip's own length (once each, < 1 %
+    of the job).  audios: list of processor-normalised waveforms [n_b]; returns (list of [1, L_b, V3] vertices, list of latents)
+    in the caller's order.  DDIM (noise-free): clips are grouped by length (least padding).  DDPM: groups follow the caller's
+    order and clip b draws the noise stream of index b (Philox key clip0 + position), so results do not depend on max_batch."""
+    model = diffusion.denoise_fn.model if isinstance(diffusion.denoise_fn, ClassifierFreeSampleModel) else diffusion.denoise_fn
+    p = model.preset
+    n = len(audios)
+    wavs = [torch.as_tensor(a, dtype=torch.float32, device=device).reshape(1, -1) for a in audios]
+    hubs = [model.audio_encoder(w).last_hidden_state for w in wavs]                 # [1, N_b, fw] each, own length
+    Ls = [min(h.shape[1] // p.pair, p.max_len) for h in hubs]
+
+    def row(x, b, width, default):
+        if x is None:
+            return default
+        x = torch.as_tensor(x[b] if isinstance(x, (list, tuple)) else x, dtype=torch.float32).reshape(-1, width)
+        return x[b:b + 1] if x.shape[0] == n else x[:1]
+    ddim = bool(ddim_steps) and not p.n_emo
+    order = sorted(range(n), key=lambda b: Ls[b]) if ddim else list(range(n))
+    verts, lats = [None] * n, [None] * n
+    prev = (model._hub_key, model._hub)
+    try:
+        for g0 in range(0, n, max_batch):
+            grp = order[g0:g0 + max_batch]
+            Lmax, Nmax = max(Ls[b] for b in grp), max(hubs[b].shape[1] for b in grp)
+            hub = torch.zeros(len(grp), Nmax, hubs[grp[0]].shape[2], device=device)
+            x_T = torch.zeros(len(grp), Lmax * p.G, p.c)
+            for i, b in enumerate(grp):
+                hub[i, :hubs[b].shape[1]] = hubs[b][0]
+                gen = torch.Generator(device="cpu").manual_seed(seed)                 # what animate() draws for this clip alone
+                x_T[i, :Ls[b] * p.G] = torch.randn((1, Ls[b] * p.G, p.c), generator=gen)[0]
+            ids = torch.cat([row(id_one_hots, b, p.n_style, torch.eye(p.n_style)[:1]) for b in grp]).to(device)
+            model.set_audio_features(hub)
+            dummy = torch.zeros(len(grp), 1, device=device)
+            shape = (len(grp), Lmax * p.G, p.c)
+            if p.n_emo:
+                emos = torch.cat([row(emotion_one_hots, b, p.n_emo, torch.eye(p.n_emo)[4:5]) for b in grp]).to(device)
+                lat = diffusion.sample(dummy, shape, emos, ids, seed=seed, x_T=x_T, clip0=g0)
+            elif ddim_steps:
+                lat = diffusion.ddim_sample(dummy, shape, ids, ddim_steps, x_T=x_T)
+            else:
+                lat = diffusion.sample(dummy, shape, ids, seed=seed, x_T=x_T, clip0=g0)
+            for i, b in enumerate(grp):
+                lb = lat[i:i + 1, :Ls[b] * p.G].contiguous()
+                q = autoencoder.quant(lb, emos[i:i + 1])[0] if p.n_emo else autoencoder.quant(lb)[0]
+                out = autoencoder.decode(q)
+                if templates is not None:
+                    tp = templates[b] if isinstance(templates, (list, tuple)) else templates
+                    out = out + torch.as_tensor(tp, dtype=torch.float32, device=device).reshape(1, 1, -1)
+                verts[b], lats[b] = out, lb
+    finally:
+        model._hub_key, model._hub = prev
+    return verts, lats
+
+
 def demo_main(preset, argv=None):
     """CLI of demo/demo_{vocaset,biwi,3d_mead}.py:109-121: same flags, output = np.save(<audio_path>/<stem>.npy, [1, L, V3])."""
     import argparse

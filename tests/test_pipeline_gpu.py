@@ -142,6 +142,42 @@ def test_style_loop_batched_equals_the_reference_loop(tmp_path):
     assert not np.array_equal(a0, a5)          # the style does change the animation
 
 
+def test_clips_of_different_lengths_batch_exactly():
+    """pipeline.animate_many: a test set's clips of different durations in ONE sampling call (padded at the end; the denoiser's
+    attention is causal, everything else per row) -- each clip's latent and vertices are bit-identical to animating it alone
+    (DDIM, the VOCASET sampler's mode), and for DDPM to the B = 1 call that draws the clip's own noise stream."""
+    from fdm_amd import pipeline, presets
+    p = presets.get("vocaset")
+    diffusion, ae = pipeline.build_models("vocaset", None, DEV)
+    g = torch.Generator().manual_seed(3)
+    audios = [pipeline.processor_normalize((torch.randn(n, generator=g) * 0.1).numpy(), pad_seconds=0) for n in (16000, 24400, 11300, 20000)]
+    ids = [torch.eye(p.n_style)[i:i + 1] for i in (2, 0, 7, 5)]
+    tmpl = [torch.full((1, p.V3), 0.01 * i) for i in range(4)]
+    verts, lats = pipeline.animate_many(diffusion, ae, audios, tmpl, ids, ddim_steps=6, device=DEV, max_batch=3)
+    assert [v.shape[1] for v in verts] == [48, 76, 34, 62]
+    for b in range(4):
+        v1, l1 = pipeline.animate(diffusion, ae, audios[b], tmpl[b], ids[b], ddim_steps=6, device=DEV)
+        assert torch.equal(l1, lats[b]) and torch.equal(v1, verts[b]), b
+    # DDPM (short chain through t_range is not exposed by animate: use the module surface): clip b draws noise stream b
+    model = diffusion.denoise_fn
+    hubs = [model.audio_encoder(torch.as_tensor(a, device=DEV).reshape(1, -1)).last_hidden_state for a in audios[:3]]
+    Ls = [h.shape[1] for h in hubs]
+    Lmax = max(Ls)
+    hub = torch.zeros(3, Lmax, 1024, device=DEV)
+    xT = torch.zeros(3, Lmax * p.G, p.c)
+    for i in range(3):
+        hub[i, :Ls[i]] = hubs[i][0]
+        xT[i, :Ls[i] * p.G] = torch.randn(Ls[i] * p.G, p.c, generator=torch.Generator().manual_seed(40 + i))
+    model.set_audio_features(hub)
+    both = diffusion.p_sample_loop((3, Lmax * p.G, p.c), torch.zeros(3, 1, device=DEV), torch.cat(ids[:3]).to(DEV), seed=9, x_T=xT, t_range=(999, 979))
+    for i in range(3):
+        model.set_audio_features(hubs[i])
+        one = diffusion.p_sample_loop((1, Ls[i] * p.G, p.c), torch.zeros(1, 1, device=DEV), ids[i].to(DEV), seed=9, x_T=xT[i:i + 1, :Ls[i] * p.G],
+                                      t_range=(999, 979), clip0=i)
+        assert torch.equal(one[0], both[i, :Ls[i] * p.G]), i
+    model._hub_key, model._hub = None, None
+
+
 def test_mead_end_to_end_animate_with_evq():
     """3D-MEAD wiring of samples/sample_diffusion_mead.py:67-86: sample(audio, shape, emo, id) -> quant(result, emo)
     -> decode; short chain (t_range) on random-init weights; checks shapes, finiteness, emotion-sliced codebook use
