@@ -107,6 +107,40 @@ def test_pingpong_tile_is_bit_identical_and_race_free(dtype):
             assert torch.equal(out, ref), f"dtype {dtype} shape {(M, N, K)} rep {rep}: max diff {float((out - ref).abs().max())}"
 
 
+def test_pingpong_tile_batched_launch_and_kv_epilogue():
+    """The ping-pong tile through the other launch forms the step uses: a batched GEMM (blockIdx.z: the CFG latent encoder,
+    shared A, per-half addend and output) and a QKV projection with the packed K / V epilogue -- the same bits as the 64x64 tile."""
+    from fdm_amd._lib import TILE_256x128_PP, TILE_64x64
+    g = torch.Generator().manual_seed(8)
+    M, N, K = 600, 512, 512
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(2 * M, N, generator=g).to(DEV)
+    outs = []
+    for tile in (TILE_64x64, TILE_256x128_PP):
+        o32 = torch.zeros(2 * M, N, device=DEV)
+        ot = torch.zeros(2 * M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(A, W, M, N, K, bias=bias, act=ACT_MISH, resid=res, out_f32=o32, out_t=ot, batch=2, out_bs=M * N, tile=tile)
+        outs.append((o32, ot))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert rel(outs[1][0][M:], act_ref(A.float().cpu().double() @ W.float().cpu().double().t() + bias.cpu(), ACT_MISH) + res[M:].cpu()) < 2e-2
+    B, H, L, hd = 3, 4, 200, 128
+    d = H * hd
+    x = torch.randn(B * L, d, generator=g).to(torch.bfloat16).to(DEV)
+    Wqkv = (torch.randn(3 * d, d, generator=g) / math.sqrt(d)).to(torch.bfloat16).to(DEV)
+    bq = (0.1 * torch.randn(3 * d, generator=g)).to(DEV)
+    packs = []
+    for tile in (TILE_64x64, TILE_256x128_PP):
+        q_t = torch.zeros(B * L, d, device=DEV, dtype=torch.bfloat16)
+        kp, vp, Lpad = ops.kv_buffers(B, H, L, hd, torch.bfloat16, DEV)
+        ops.gemm(x, Wqkv, B * L, 3 * d, d, bias=bq, out_t=q_t, ldo_t=d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=Lpad,
+                 kv_hd=hd, tile=tile)
+        packs.append((q_t, kp, vp))
+    for a_, b_ in zip(packs[0], packs[1]):
+        assert torch.equal(a_, b_)
+
+
 def test_split_producers_write_plane_pairs():
     """LayerNorm, scheduler and fp32 attention write GEMM inputs as plane pairs in the split modes."""
     g = torch.Generator().manual_seed(3)
