@@ -317,6 +317,18 @@ def main():
                                       "what": f"{S} sequential B = 1 calls per clip (samples/sample_diffusion_vocaset.py:71-83)",
                                       "bit_identical_to_batched": bool(torch.equal(out_s, out))}
             leg["speedup_vs_sequential_loop"] = round(el_s / el, 3)
+        if world > 1 and rank == 0 and not e2e and S == 1 and not a.profile_steps:
+            # N > 1 self-check, outside the timed region: rank 0 recomputes the LAST rank's clips (same global clip indices, so the
+            # same Philox streams) and compares them with what the collective delivered -- cross-rank determinism and the gather
+            # order, verified on the hardware the line was measured on
+            r = world - 1
+            slr = slice(r * B, (r + 1) * B)
+            hub_r = inp["hub"][slr][:, :, :768].contiguous() if preset == "biwi" else inp["hub"][slr]
+            plan.prepare(hub_r, inp["style"][slr], inp["emo"][slr] if "emo" in inp else None, L=L, cfg=cfg)
+            xr = inp["x"][slr].to(dev)
+            mine = plan.sample_ddpm(xr, ts, seed=1234, clip0=r * B) if sampler == "ddpm" else plan.sample_ddim(xr, T)
+            leg["shard_check"] = {"rank": r, "bit_identical": bool(torch.equal(mine.to(out.device), out[slr]))}
+            prep()
         if want_parity and preset == "vocaset" and rank == 0:
             leg["parity_max_abs"] = parity_vs_reference(plan, dev)
         return leg, plan, out
@@ -397,7 +409,7 @@ def main():
             "gemm_tiles": head["gemm_tiles"],
             "roofline": head["roofline"],
         }
-        for k in ("sequential_loop", "speedup_vs_sequential_loop"):
+        for k in ("sequential_loop", "speedup_vs_sequential_loop", "shard_check"):
             if k in head:
                 res[k] = head[k]
         if "parity_max_abs" in head:

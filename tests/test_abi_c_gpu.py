@@ -98,6 +98,7 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["global_batch"] == 2
     assert rec["rccl_ranks"] == 2 and rec["dist_backend"] == "gloo"        # self-checking: the line says how many ranks really ran
+    assert rec["shard_check"] == {"rank": 1, "bit_identical": True}        # rank 0 recomputed rank 1's clip: the line verifies itself
     assert rec["weights"].startswith("broadcast")        # rank 1 started from another seed: bit-equal outputs below prove the broadcast
     assert rec["parity"]["max_abs"] < 1e-4 and rec["parity"]["dtype"] == "f32"
     a, b = np.load(one), np.load(two)
