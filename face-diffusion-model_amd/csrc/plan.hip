@@ -671,18 +671,31 @@ struct ProgSpec {
   int reps = 1;              // diffusion steps recorded back to back (one graph launch runs them all)
 };
 
+// Recorded programs are kept per (shape, tile set, program kind): a serving loop that alternates between shapes (clips of
+// different lengths, one clip vs a batch) finds its graphs again instead of re-recording and re-instantiating them (~3 ms per
+// switch).  What a program captured stays valid until the workspaces are re-allocated or the weights / tables change: those
+// events drop every program.
+std::string tiles_sig(const fdm_plan* P) {
+  std::string s;
+  for (auto& kv : P->tiles)
+    if (kv.second) s += kv.first + "=" + std::to_string(kv.second) + ",";
+  return s;
+}
+
 int get_program(fdm_plan* P, const ProgSpec& sp, void* stream, fdm_prog** out) {
-  char key[256];
-  snprintf(key, sizeof(key), "%d|%p|%a|%p|%d", sp.kind, (const void*)sp.noise, (double)sp.cfg_scale, (const void*)sp.san, sp.reps);
+  char key[512];
+  snprintf(key, sizeof(key), "%s#%s|%d|%p|%a|%p|%d", shape_key(P).c_str(), tiles_sig(P).c_str(), sp.kind, (const void*)sp.noise, (double)sp.cfg_scale,
+           (const void*)sp.san, sp.reps);
   auto it = P->progs.find(key);
   if (it != P->progs.end()) {            // hit: most recently used goes to the back, and the caller's handle stays valid for this call
     auto pos = std::find(P->prog_order.begin(), P->prog_order.end(), std::string(key));
     if (pos != P->prog_order.end()) { P->prog_order.erase(pos); P->prog_order.push_back(key); }
     P->pinned.push_back(key);
+    if (sp.reps == 1) P->launches_per_step = fdm_prog_num_ops(it->second);
     *out = it->second;
     return FDM_OK;
   }
-  if (P->progs.size() >= 8) {
+  if (P->progs.size() >= 16) {
     // programs are keyed by the pointers they captured (e.g. injected noise): cap the cache.  Victim = least recently used
     // program that was NOT handed out earlier in this API call (fdm_sample_graph holds two: the 1-step and the K-step one).
     auto victim = P->prog_order.end();
@@ -1053,9 +1066,8 @@ int fdm_audio_prepare_conds(fdm_plan* P, const float* hub, int B0, int N, int fw
   const int B = B0 * S;                      // row blocks of the step program
   FCK(commit(P, stream));
   FCK(reserve(P, B, L, cfg));
-  // recorded programs hold the workspace pointers and the shape, not the clip tables' contents: a new batch of the same
-  // shape (serving) keeps them and their instantiated graphs
-  if (!(P->prepared && P->B == B && P->S == S && P->L == L && P->cfg == (cfg ? 1 : 0))) FCK(drop_programs(P, stream));
+  // recorded programs hold the workspace pointers and the shape, not the clip tables' contents: a new batch of a shape seen
+  // before (serving) finds them and their instantiated graphs again (get_program keys them by shape and tile set)
   hipStream_t s = (hipStream_t)stream;
   const int d = m.d, M0 = B0 * L, M = B * L, rep = cfg ? 2 : 1;
   P->B = B; P->S = S; P->L = L; P->M = M; P->rep = rep; P->R = M * rep; P->cfg = cfg ? 1 : 0; P->Lpad = (L + 31) / 32 * 32;
@@ -1107,7 +1119,7 @@ int fdm_audio_prepare_conds(fdm_plan* P, const float* hub, int B0, int N, int fw
   std::map<std::string, int> want;
   if (it != P->tile_cache.end()) want = it->second;
   else apply_tile_override(want);          // FDM_TILE_OVERRIDE pins tiles with or without the tuner (heuristic tiles elsewhere)
-  if (want != P->tiles) { FCK(drop_programs(P, stream)); P->tiles = want; }
+  P->tiles = want;                          // (programs are keyed by the tile set they were recorded with)
   return tune_tiles(P, 0, stream);        // plan-time: only for a shape that has already served >= 2000 steps untuned
 }
 

@@ -392,15 +392,16 @@ def test_condition_batching_validates_arguments():
 
 
 def test_program_cache_never_evicts_a_program_in_use():
-    """sweeping graph_steps fills the 8-entry program cache; the 1-step program fetched first must survive the
-    insertion of the K-step program in the same call (it replays the n_steps % K tail)."""
+    """sweeping graph_steps overflows the program cache (16 entries, LRU, keyed by shape / tile set / kind); the
+    1-step program fetched first must survive the insertion of the K-step program in the same call (it replays the
+    n_steps % K tail)."""
     plan, _ = plan_for("vocaset_tiny", F32)
     L = 12
     inp = W.synth_inputs("vocaset_tiny", 1, L, seed=2)
     plan.prepare(inp["hub"], inp["style"], L=L)
     ts = list(range(999, 999 - 23, -1))
     ref = plan.sample_ddpm(inp["x"].to(DEV), ts, seed=3, use_graph=False).cpu()
-    for k in (2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 2, 9):
+    for k in list(range(2, 23)) + [2, 9, 22, 3]:
         out = plan.sample_ddpm(inp["x"].to(DEV), ts, seed=3, graph_steps=k).cpu()
         assert torch.equal(out, ref), f"graph_steps={k}"
 
@@ -469,3 +470,23 @@ def test_tile_override_applies_at_prepare_and_tuning_is_plan_time(monkeypatch):
     for _ in range(3):
         plan3.sample_ddpm(inp["x"].to(DEV), ts, seed=1)
     assert plan3.get("tuned") == 1                      # opted in: the third call (2000 steps seen) tuned in-call
+
+
+def test_programs_are_kept_per_shape():
+    """A serving loop that alternates between shapes finds its recorded programs again (keyed by shape and tile set) and gets the
+    same bits as a fresh plan; a weight update still drops everything."""
+    w = W.make_fdm_weights("vocaset_tiny")
+    plan = DenoiserPlan("vocaset_tiny", w, F32, DEV)
+    inpA, inpB = W.synth_inputs("vocaset_tiny", 2, 20, seed=1), W.synth_inputs("vocaset_tiny", 1, 33, seed=2)
+    ts = list(range(999, 979, -1))
+    refs = {}
+    for rnd in range(3):
+        for name, inp, L in (("A", inpA, 20), ("B", inpB, 33)):
+            plan.prepare(inp["hub"], inp["style"], L=L)
+            out = (plan.sample_ddpm(inp["x"].to(DEV), ts, seed=4).cpu(), plan.sample_ddim(inp["x"].to(DEV), 7).cpu())
+            if name in refs:
+                assert torch.equal(out[0], refs[name][0]) and torch.equal(out[1], refs[name][1]), (rnd, name)
+            refs[name] = out
+    fresh = DenoiserPlan("vocaset_tiny", w, F32, DEV)
+    fresh.prepare(inpB["hub"], inpB["style"], L=33)
+    assert torch.equal(fresh.sample_ddpm(inpB["x"].to(DEV), ts, seed=4).cpu(), refs["B"][0])
