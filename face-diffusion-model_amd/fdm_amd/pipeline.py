@@ -119,7 +119,7 @@ def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emoti
 
 @torch.no_grad()
 def animate_many(diffusion, autoencoder, audios, templates=None, id_one_hots=None, emotion_one_hots=None, ddim_steps=None,
-                 seed=0, device="cuda:0", max_batch=8):
+                 seed=0, device="cuda:0", max_batch=8, bucket=16):
     """A test set's clips (different durations) through ONE sampling call per group of `max_batch` clips.
 
     The reference's samplers take the clips of a loader one at a time (bs = 1: samples/sample_diffusion_vocaset.py:51,71-83),
@@ -130,7 +130,9 @@ def animate_many(diffusion, autoencoder, audios, templates=None, id_one_hots=Non
     discarded.  The audio encoder and the VQ decoder are not causal: they run per clip at the clip's own length (once each, < 1 %
     of the job).  audios: list of processor-normalised waveforms [n_b]; returns (list of [1, L_b, V3] vertices, list of latents)
     in the caller's order.  DDIM (noise-free): clips are grouped by length (least padding).  DDPM: groups follow the caller's
-    order and clip b draws the noise stream of index b (Philox key clip0 + position), so results do not depend on max_batch."""
+    order and clip b draws the noise stream of index b (Philox key clip0 + position), so results do not depend on max_batch.
+    A group's length is rounded up to a multiple of `bucket` frames (free: the padding is exact), so a long-running caller
+    cycles through a handful of shapes whose recorded step programs and tuned tiles the plan keeps."""
     model = diffusion.denoise_fn.model if isinstance(diffusion.denoise_fn, ClassifierFreeSampleModel) else diffusion.denoise_fn
     p = model.preset
     n = len(audios)
@@ -150,7 +152,10 @@ def animate_many(diffusion, autoencoder, audios, templates=None, id_one_hots=Non
     try:
         for g0 in range(0, n, max_batch):
             grp = order[g0:g0 + max_batch]
-            Lmax, Nmax = max(Ls[b] for b in grp), max(hubs[b].shape[1] for b in grp)
+            Lmax = max(Ls[b] for b in grp)
+            if bucket and bucket > 1:
+                Lmax = min(-(-Lmax // bucket) * bucket, p.max_len)
+            Nmax = max(max(hubs[b].shape[1] for b in grp), Lmax * p.pair)
             hub = torch.zeros(len(grp), Nmax, hubs[grp[0]].shape[2], device=device)
             x_T = torch.zeros(len(grp), Lmax * p.G, p.c)
             for i, b in enumerate(grp):
