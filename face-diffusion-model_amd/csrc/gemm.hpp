@@ -605,19 +605,24 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #ifndef FDM_PP_VARIANT
 #define FDM_PP_VARIANT 0      // tools/pp_probe.cpp only: bit 0 = no MFMAs, bit 1 = no fragment reads, bit 2 = no DMA after the prologue
 #endif
-template <typename T, int BM, int BN, int WM, int WN, int NST, bool HEAVY = false, bool SCHED = false, int SPEC = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool HEAVY = false, bool SCHED = false, int SPEC = 0, int KCH = 8>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
   using E = typename Opnd<T>::E;
   static_assert(WM * WN == 8, "ping-pong loop: two groups of four waves");
   constexpr int NP = Opnd<T>::NP;
-  constexpr int KCH = 8, NW = 8, ROWB = 128, RPI = 8;
+  // KCH = 16-byte chunks of K per LDS row: 8 (64-deep stages, two k-steps) or 4 (32-deep stages, one k-step: half the bytes
+  // per stage, so a 256x256 tile gets a 4-stage ring in 128 KB)
+  static_assert(KCH == 8 || KCH == 4, "LDS rows of 128 or 64 bytes");
+  constexpr int NW = 8, ROWB = KCH * 16, RPI = 1024 / ROWB, KS = KCH / 4;
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   constexpr int A_IPW = BM / RPI / NW, W_IPW = BN / RPI / NW;
   static_assert(A_IPW >= 1 && W_IPW >= 1 && MI >= 1 && NI >= 1, "tile too small for the wave grid");
   constexpr int P = NP * (A_IPW + W_IPW);          // DMA pieces per wave and k-tile
   constexpr int D = NST - 1;                       // k-tiles in flight
   constexpr int STAGE = NP * (BM + BN) * ROWB;
-  static_assert(NST >= 2 && NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>(), "epilogue staging does not fit in the ring");
+  // (the ring doubles as the epilogue's staging area only in the kernels that can pack V or fold a LayerNorm)
+  constexpr bool EPI_RING = !(SPEC & GEMM_LEAN) || (SPEC & (GEMM_KV | GEMM_FOLD));
+  static_assert(NST >= 2 && (!EPI_RING || NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>()), "epilogue staging does not fit in the ring");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* rowstat = (float*)(smem + NST * STAGE);
 #ifdef FDM_PP_PHASES
@@ -649,18 +654,21 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
   const E* W = (const E*)p.W + (size_t)z * p.w_batch_stride;
   const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);
 
+  // 16-byte-chunk swizzle of a row: 128-B rows chunk ^ (row % 8); 64-B rows (four rows per 256-B bank line) chunk ^ f(row / 4 % 4)
+  // with f = {0, 2, 3, 1}: the 16 lanes of every ds_read_b128 group then hit 16 different 16-byte slots
+  auto swz = [](int row) { return KCH == 8 ? (row & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
   const int lrow = lane / KCH, slot = lane % KCH;
   const char* a_src[A_IPW];
   const char* w_src[W_IPW];
 #pragma unroll
   for (int i = 0; i < A_IPW; ++i) {
     const int row = RPI * (wave * A_IPW + i) + lrow;
-    a_src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * p.lda) + ((slot ^ (row % KCH)) << 4);
+    a_src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * p.lda) + ((slot ^ swz(row)) << 4);
   }
 #pragma unroll
   for (int i = 0; i < W_IPW; ++i) {
     const int row = RPI * (wave * W_IPW + i) + lrow;
-    w_src[i] = (const char*)(W + (size_t)min(n0 + row, N - 1) * p.ldw) + ((slot ^ (row % KCH)) << 4);
+    w_src[i] = (const char*)(W + (size_t)min(n0 + row, N - 1) * p.ldw) + ((slot ^ swz(row)) << 4);
   }
   auto issue = [&](int kt) {
     char* sb = smem + (kt % NST) * STAGE;
@@ -698,18 +706,18 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int row = wm * (BM / WM) + mi * 16 + r16;
-    a_off[mi] = row * ROWB + ((g ^ (row % KCH)) << 4);
+    a_off[mi] = row * ROWB + ((g ^ swz(row)) << 4);
   }
 #pragma unroll
   for (int ni = 0; ni < NI; ++ni) {
     const int row = wn * (BN / WN) + ni * 16 + r16;
-    w_off[ni] = (NP * BM + row) * ROWB + ((g ^ (row % KCH)) << 4);
+    w_off[ni] = (NP * BM + row) * ROWB + ((g ^ swz(row)) << 4);
   }
-  u32x4 af[2][MI][NP], wf[2][NI][NP];
+  u32x4 af[KS][MI][NP], wf[KS][NI][NP];
   auto load_frags = [&](int kt) {
     const char* base = smem + (kt % NST) * STAGE;
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
@@ -720,7 +728,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
   };
   auto compute = [&]() {
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -773,7 +781,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
       compute();
     } else if constexpr (!(FDM_PP_VARIANT & 2)) {      // keep the fragment reads alive
 #pragma unroll
-      for (int s = 0; s < 2; ++s) {
+      for (int s = 0; s < KS; ++s) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(af[s][mi][0]));
 #pragma unroll
@@ -801,9 +809,23 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
   }
   // the epilogue operands are fetched after the k loop here (one exposed round trip per workgroup, against 16+ k-tiles of
   // work): held across the loop they would cost MI * NI * 4 registers beside the accumulators and the fragment set
-  EpiPre<MI, NI> epre;
-  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
-  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+  if constexpr (MI > 4 && !EPI_RING) {
+    // 128-row wave tiles: the epilogue's operand preload (MI x NI residual fragments) would not fit beside the accumulators, so it
+    // runs over the wave's rows in two halves -- the lean epilogue only needs each row's global index, which the per-wave row
+    // base carries (a tile of BM / 2 rows with this wave's rows shifted into place)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      f32x4 (&acch)[MI / 2][NI] = *reinterpret_cast<f32x4 (*)[MI / 2][NI]>(&acc[hh * (MI / 2)]);
+      const int m0h = m0 + wm * (BM / WM) - wm * (BM / 2 / WM) + hh * (BM / 2 / WM);
+      EpiPre<MI / 2, NI> epre;
+      gemm_epi_preload<T, BM / 2, BN, WM, WN, SCHED>(p, m0h, n0, z, wm, wn, g, r16, false, epre);
+      gemm_epilogue<T, BM / 2, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acch, epre, m0h, n0, z, wm, wn, g, r16, nullptr, nullptr);
+    }
+  } else {
+    EpiPre<MI, NI> epre;
+    gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
+    gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+  }
 #ifdef FDM_PP_PHASES
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -811,16 +833,16 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
 #endif
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, bool HEAVY, bool SCHED = false, int SPEC = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool HEAVY, bool SCHED = false, int SPEC = 0, int KCH = 8>
 static hipError_t gemm_pp_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
-  constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * 128 + gemm_ln_scratch_bytes<BM, BN>();
+  constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
   static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
   static bool once = [] {
-    return hipFuncSetAttribute((const void*)gemm_pp_kernel<T, BM, BN, WM, WN, NST, HEAVY, SCHED, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    return hipFuncSetAttribute((const void*)gemm_pp_kernel<T, BM, BN, WM, WN, NST, HEAVY, SCHED, SPEC, KCH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_pp_kernel<T, BM, BN, WM, WN, NST, HEAVY, SCHED, SPEC>), grid, dim3(512), lds, s, a);
+  hipLaunchKernelGGL((gemm_pp_kernel<T, BM, BN, WM, WN, NST, HEAVY, SCHED, SPEC, KCH>), grid, dim3(512), lds, s, a);
   return hipGetLastError();
 }
 

@@ -22,6 +22,9 @@
 #define PP_WN 2
 #define PP_NST 3
 #endif
+#ifndef PP_KCH
+#define PP_KCH 8
+#endif
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 8192, N = argc > 2 ? atoi(argv[2]) : 1024, K = argc > 3 ? atoi(argv[3]) : 2048;
@@ -45,7 +48,7 @@ int main(int argc, char** argv) {
   a.out_f32 = out; a.ldo_f32 = N; a.ldr = N; a.ldo_t = N; a.ln_eps = 1e-5f;
   auto run = [&](int i) {
     a.W = W[i % 8];
-    hipError_t e = fdm::gemm_pp_launch_h<fdm::bf16, PP_BM, PP_BN, PP_WM, PP_WN, PP_NST, false, false, fdm::GEMM_LEAN>(a, s);
+    hipError_t e = fdm::gemm_pp_launch_h<fdm::bf16, PP_BM, PP_BN, PP_WM, PP_WN, PP_NST, false, false, fdm::GEMM_LEAN, PP_KCH>(a, s);
     if (e != hipSuccess) { printf("launch: %s\n", hipGetErrorString(e)); exit(1); }
   };
 #ifdef FDM_PP_PHASES
@@ -128,7 +131,7 @@ int main(int argc, char** argv) {
   CK(hipEventSynchronize(e1));
   float ms = 0.f;
   CK(hipEventElapsedTime(&ms, e0, e1));
-  const double us = ms * 1e3 / reps, nk = K / 64.0;
+  const double us = ms * 1e3 / reps, nk = K / (PP_KCH * 8.0);
   printf("variant %d tile %dx%d M=%d N=%d K=%d: %.2f us per launch, %.3f us per k-tile, %.1f TFLOP/s if it were the full kernel\n", FDM_PP_VARIANT,
          PP_BM, PP_BN, M, N, K, us, us / nk, 2.0 * M * N * K / us / 1e6);
   return 0;
