@@ -312,11 +312,13 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   {
     constexpr int TPQ = 256 / BQ;                    // threads per query row (16 or 8)
     constexpr int EPT = HD / TPQ;                    // head-dim elements per thread (multiple of 4)
-    // a thread takes EPT / 4 float4 pieces TPQ * 4 floats apart: the lanes of a read group then sit on consecutive 16-byte
-    // slots (conflict-free for every head dim; the contiguous-run mapping was 2-way conflicted at head dim 256) and a wave's
-    // store covers whole 256-byte runs of an output row
+    // A thread takes runs of RUN consecutive floats, EPT / RUN of them TPQ * RUN floats apart.  RUN = EPT (one contiguous run)
+    // is conflict-free with the +4 row pad up to 8 floats per thread (measured: SQ_LDS_BANK_CONFLICT 0 at head dim 64 / 128);
+    // 16 contiguous floats per thread (head dim 256) put lanes l and l + 4 of a read group on one 16-byte slot (21 % of the
+    // kernel's LDS cycles), so that case reads two runs of 8, i.e. the head-dim-128 pattern twice.
+    constexpr int RUN = (EPT == 16 && TPQ == 16) ? 8 : EPT;
     const int q = threadIdx.x / TPQ;
-    const int e0 = (threadIdx.x % TPQ) * 4;
+    const int e0 = (threadIdx.x % TPQ) * RUN;
     const int qq = q0 + q;
     float mw[4], ms = -INFINITY;
 #pragma unroll
@@ -328,8 +330,10 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
     if (qq < L) {
       const size_t oo = ((size_t)b * L + qq) * p.ldo + (size_t)h * HD + e0;
 #pragma unroll
-      for (int jj = 0; jj < EPT / 4; ++jj) {
-        const int j = jj * TPQ * 4;
+      for (int rr = 0; rr < EPT / RUN; ++rr)
+#pragma unroll
+      for (int jj = 0; jj < RUN; jj += 4) {
+        const int j = rr * TPQ * RUN + jj;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < 4; ++w) v += *(const f32x4*)&part_o[w][q][e0 + j] * sw[w];
