@@ -404,9 +404,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   constexpr int ROWB = KCH * 16;                 // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;               // rows written by one wave-wide LDS-DMA instruction
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
-  constexpr int A_IPW = BM / RPI / NW, W_IPW = BN / RPI / NW;     // glds instructions per wave per k-tile and plane
-  static_assert(A_IPW >= 1 && W_IPW >= 1 && MI >= 1 && NI >= 1, "tile too small for the wave grid");
-  constexpr int P = NP * (A_IPW + W_IPW);
+  // glds instructions (1 KB pieces) per wave, k-tile and plane.  A tile whose A pieces do not divide by the wave count (80 rows =
+  // 10 pieces on 8 waves) deals them out strided -- piece i * NW + wave -- and the first NA % NW waves carry one more: their
+  // counted waits use their own piece count (a wave-uniform branch).
+  constexpr int NA = BM / RPI, NWP = BN / RPI;
+  constexpr bool UNEVEN = NA % NW != 0;
+  static_assert(NWP % NW == 0 && BM % RPI == 0 && MI >= 1 && NI >= 1, "tile does not fit the wave grid");
+  constexpr int A_IPW = (NA + NW - 1) / NW, W_IPW = NWP / NW;
+  constexpr int P = NP * (A_IPW + W_IPW), P_LO = NP * (A_IPW - 1 + W_IPW);
   constexpr int STAGE = NP * (BM + BN) * ROWB;   // [A planes][W planes]
   static_assert(NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>(), "epilogue staging does not fit in the ring");
   constexpr bool EARLY_READS = NP * (KCH / 4) * (MI + NI) <= 12;     // fragment registers for a whole k-tile
@@ -443,7 +448,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   const char* w_src[W_IPW];
 #pragma unroll
   for (int i = 0; i < A_IPW; ++i) {
-    const int row = RPI * (wave * A_IPW + i) + lrow;
+    const int piece = UNEVEN ? min(i * NW + wave, NA - 1) : wave * A_IPW + i;
+    const int row = RPI * piece + lrow;
     a_src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * p.lda) + ((slot ^ (row % KCH)) << 4);
   }
 #pragma unroll
@@ -457,8 +463,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #pragma unroll
     for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-      for (int i = 0; i < A_IPW; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (wave * A_IPW + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < A_IPW; ++i) {
+        if constexpr (UNEVEN) {
+          if (i * NW + wave < NA)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (i * NW + wave) * 1024), 16, 0, 0);
+        } else {
+          __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (wave * A_IPW + i) * 1024), 16, 0, 0);
+        }
+      }
 #pragma unroll
       for (int i = 0; i < W_IPW; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(w_src[i] + off + pl * w_lo), (lptr_t)(sb + (NP * BM + pl * BN) * ROWB + (wave * W_IPW + i) * 1024), 16, 0, 0);
@@ -510,8 +522,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most the (NST-2) younger tiles of this wave are still in flight
-    if (kt + NST - 2 < nk) wait_vmcnt<(NST - 2) * P>();
-    else wait_vmcnt<0>();
+    if (kt + NST - 2 < nk) {
+      if (!UNEVEN || wave < NA % NW) wait_vmcnt<(NST - 2) * P>();
+      else wait_vmcnt<(NST - 2) * P_LO>();
+    } else {
+      wait_vmcnt<0>();
+    }
     __builtin_amdgcn_s_barrier();           // everyone's part of tile kt landed; stage (kt-1)%NST is free
 #ifdef FDM_GEMM_STAMPS
     if (stamps && tid == 0 && kt == 0) stamps[1] = wall_clock64();
@@ -919,6 +935,14 @@ static int gemm_tile_override() {
   return v;
 }
 
+// 80x128 tiles that fill the chip in exactly one round (225..256 workgroups, e.g. 800 rows x 3072 columns = 240): every CU
+// streams one (80 + 128)-row operand pair instead of two or three 64x64 ones (12.7 vs 14.6 us bf16, 22.2 vs 28.4 us f16x3
+// on that shape; profiles/README.md round 3)
+static bool gemm_one_round_80(const fdm_gemm_args& a) {
+  const long long t80 = (long long)((a.M + 79) / 80) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
+  return t80 > 224 && t80 <= 256 && (a.M % 80 == 0 || a.M % 80 > 40);   // (a mostly empty last row tile wastes the round)
+}
+
 template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   const long long batch = a.batch > 0 ? a.batch : 1;
@@ -941,6 +965,8 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 32 KB -> 4 workgroups per CU
     case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);    // 4 waves, 16x32 per wave, 36 KB
     case FDM_TILE_256x128_PP: return gemm_pp_launch_t<T, 256, 128, 4, 2, 3>(a, s);   // ping-pong loop, 64x64 per wave, 146 KB
+    case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);      // 8 waves, 80x16 per wave: 800 rows x 3072 = 240 workgroups
+    case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4>(a, s);      // 8 waves, 32x32 per wave
     default: break;
   }
   // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;
@@ -949,6 +975,7 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   static const long long thr128 = [] { const char* e = getenv("FDM_GEMM_T128"); return e ? atoll(e) : 512LL; }();
   static const long long thr128x64 = [] { const char* e = getenv("FDM_GEMM_T128X64"); return e ? atoll(e) : 700LL; }();
   if (t128 >= thr128) return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
+  if (gemm_one_round_80(a)) return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);
   if (t128x64 >= thr128x64) return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);  // 8 waves, 32x32 per wave
   return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                       // 8 waves, 32x16 per wave
 }
@@ -974,11 +1001,14 @@ static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
       case FDM_TILE_128x128:
       case FDM_TILE_96x128:
       case FDM_TILE_256x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);    // 128 KB, one tile in flight
+      case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);      // 156 KB
+      case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 3>(a, s);      // 144 KB
       default: break;
     }
     const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
     const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
     if (t128 >= 512) return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);
+    if (gemm_one_round_80(a)) return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);
     if (t128x64 >= 700) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);
     return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);
   }

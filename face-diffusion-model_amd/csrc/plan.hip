@@ -879,8 +879,8 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
     return FDM_OK;
   };
   std::vector<int> cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64, FDM_TILE_128x64_S3,
-                            FDM_TILE_128x128, FDM_TILE_96x128};
-  if (is_split(P->dtype)) cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64_S3, FDM_TILE_128x128};
+                            FDM_TILE_128x128, FDM_TILE_96x128, FDM_TILE_80x128, FDM_TILE_64x128};
+  if (is_split(P->dtype)) cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64_S3, FDM_TILE_128x128, FDM_TILE_80x128, FDM_TILE_64x128};
   else if (P->R >= 1024) { cands.push_back(FDM_TILE_256x128); cands.push_back(FDM_TILE_256x128_PP); }
   // Which of them are worth a stopwatch is decided by a wave-quantisation model first.  What bounds these GEMMs is the
   // bytes a CU pulls from L2 into LDS: a BM x BN tile costs (BM + BN) * K * bytes-per-element (x planes)
@@ -899,6 +899,8 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
       case FDM_TILE_128x64_S3: return {128, 64, 3};
       case FDM_TILE_128x128: return {128, 128, sp ? 2 : 3};
       case FDM_TILE_96x128: return {96, 128, 4};
+      case FDM_TILE_80x128: return {80, 128, sp ? 3 : 4};
+      case FDM_TILE_64x128: return {64, 128, sp ? 3 : 4};
       case FDM_TILE_256x128:
       case FDM_TILE_256x128_PP: return {256, 128, 3};
       default: return {64, 64, 4};

@@ -39,7 +39,7 @@ class GemmArgs(C.Structure):
                 ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll)]
 
 
-TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP, TILE_80x128, TILE_64x128 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 
 
 class ModelDesc(C.Structure):

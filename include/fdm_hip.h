@@ -165,7 +165,9 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_64x64_S2 8   /* 64x64 with a 2-stage ring (four workgroups per CU) */
 #define FDM_TILE_32x64_S3 9   /* 32x64 on 4 waves, 3-stage ring: twice the workgroups of 64x64 for few-hundred-row GEMMs */
 #define FDM_TILE_256x128_PP 10 /* 256x128, two wave groups half a period apart (one computes while the other loads): large M */
-#define FDM_TILE_MAX 10
+#define FDM_TILE_80x128 11     /* 80x128: ten row tiles for 800 rows -> 240 workgroups at N = 3072 (the QKV projection of four 200-frame clips) */
+#define FDM_TILE_64x128 12     /* 64x128: 13 row tiles for 800 rows -> 208 workgroups at N = 2048 in one round (FFN1 in the split modes) */
+#define FDM_TILE_MAX 12
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------

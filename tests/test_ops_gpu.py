@@ -141,6 +141,53 @@ def test_pingpong_tile_batched_launch_and_kv_epilogue():
         assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("dtype", [BF16, F32, F16X3])
+def test_one_round_tiles_are_bit_identical(dtype):
+    """FDM_TILE_80x128 (ten A pieces over eight waves: the first two waves carry one more LDS-DMA piece per stage and wait on
+    their own count) and FDM_TILE_64x128, sized so that 800 rows fill the 256 CUs in ONE round (240 / 208 workgroups): the
+    same bits as the 64x64 tile on interior and ragged shapes, repeated (a wait-count slip shows as a run-to-run difference),
+    and through the QKV projection's packed K / V epilogue where an 80-row tile straddles the 200-frame clip boundary."""
+    from fdm_amd._lib import TILE_80x128, TILE_64x128, TILE_64x64
+    g = torch.Generator().manual_seed(80)
+    k_unit = 32 if dtype == F32 else 64
+    shapes = [(80, 128, k_unit), (800, 3072, 1024), (800, 2048, 1024), (801, 200, 3 * k_unit), (79, 384, 2 * k_unit), (1992, 1024, 2048), (2400, 3072, 1024)]
+    for (M, N, K) in shapes:
+        A = ops.to_operand(torch.randn(M, K, generator=g).to(DEV), dtype)
+        W = ops.to_operand((torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV), dtype)
+        bias = torch.randn(N, generator=g).to(DEV)
+        res = torch.randn(M, N, generator=g).to(DEV)
+        ref = torch.zeros(M, N, device=DEV)
+        ops.gemm(A, W, M, N, K, bias=bias, act=ACT_GELU_ERF, resid=res, out_f32=ref, tile=TILE_64x64)
+        for tile in (TILE_80x128, TILE_64x128):
+            for rep in range(5):
+                out = torch.full((M, N), float("nan"), device=DEV)
+                ops.gemm(A, W, M, N, K, bias=bias, act=ACT_GELU_ERF, resid=res, out_f32=out, tile=tile)
+                assert torch.equal(out, ref), f"dtype {dtype} tile {tile} shape {(M, N, K)} rep {rep}"
+    if dtype == F32:
+        return
+    B, H, L, hd = 4, 4, 200, 128
+    d = H * hd
+    x32 = torch.randn(B * L, d, generator=g).to(DEV)
+    w32 = (torch.randn(3 * d, d, generator=g) / math.sqrt(d)).to(DEV)
+    x, Wqkv = ops.to_operand(x32, dtype), ops.to_operand(w32, dtype)
+    bq = (0.1 * torch.randn(3 * d, generator=g)).to(DEV)
+    packs = []
+    for tile in (TILE_64x64, TILE_80x128, TILE_64x128):
+        q_t = ops.Split.empty(B * L, d, dtype, DEV) if dtype == F16X3 else torch.zeros(B * L, d, device=DEV, dtype=torch.bfloat16)
+        if dtype == F16X3:
+            Lpad = ops.kv_pad(L)
+            kp = ops.Split(torch.zeros(2, B * H, Lpad * hd, device=DEV, dtype=torch.float16), F16X3)
+            vp = ops.Split(torch.zeros(2, B * H, Lpad * hd, device=DEV, dtype=torch.float16), F16X3)
+        else:
+            kp, vp, Lpad = ops.kv_buffers(B, H, L, hd, torch.bfloat16, DEV)
+        ops.gemm(x, Wqkv, B * L, 3 * d, d, bias=bq, out_t=q_t, ldo_t=d, out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=Lpad,
+                 kv_hd=hd, tile=tile)
+        packs.append(tuple(t.planes if dtype == F16X3 else t for t in (q_t, kp, vp)))
+    for other in packs[1:]:
+        for a_, b_ in zip(packs[0], other):
+            assert torch.equal(a_, b_)
+
+
 def test_split_producers_write_plane_pairs():
     """LayerNorm, scheduler and fp32 attention write GEMM inputs as plane pairs in the split modes."""
     g = torch.Generator().manual_seed(3)
