@@ -289,7 +289,7 @@ def main():
                "ms_per_step": round(el / steps * 1e3, 3),
                "diffusion_steps_per_s": round(n_launch / (ev_ms * 1e-3), 1),
                "kernel_launches_per_diffusion_step": plan.get("launches_per_step"),
-               "host_graph_launches_per_sample": plan.get("graph_launches"),
+               "host_graph_launches_per_sample": plan.get("graph_launches"), "denoiser_steps_per_sample": n_live,
                "gemm_tiles": {k: v for k, v in plan.tiles.items() if v},      # plan-time choice per call site (FDM_TILE_*; others: heuristic)
                "roofline": {"bound": "mfma", "kernel": "denoiser step graph (one diffusion step, all kernels)",
                             "achieved": round(ach, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s",
@@ -406,6 +406,7 @@ def main():
             "diffusion_steps_per_s": head["diffusion_steps_per_s"],
             "kernel_launches_per_diffusion_step": head["kernel_launches_per_diffusion_step"],
             "host_graph_launches_per_sample": head["host_graph_launches_per_sample"],
+            "denoiser_steps_per_sample": head["denoiser_steps_per_sample"],
             "gemm_tiles": head["gemm_tiles"],
             "roofline": head["roofline"],
         }

@@ -7,12 +7,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
 STEPS=${PMC_STEPS:-30}
 cd /tmp; export TMPDIR=/tmp
+live() { grep -o '"denoiser_steps_per_sample": [0-9]*' $1 | grep -o '[0-9]*$'; }   # DDIM skips its dead last pair: T - 1 live steps
 pass() { # name, counters...
   local name=$1; shift
   rm -rf $OUT/raw_$name
   timeout 900 rocprofv3 --pmc "$@" --output-format csv -d $OUT/raw_$name -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --profile-steps $STEPS $BENCH_ARGS > $OUT/$name.log 2>&1
   local f=$(find $OUT/raw_$name -name "*counter_collection.csv" | head -1)
-  if [ -n "$f" ]; then python3 $ROOT/tools/pmc_report.py reduce $f $OUT/$name.csv $STEPS $(grep -o '"kernel_launches_per_diffusion_step": [0-9]*' $OUT/$name.log | grep -o '[0-9]*$'); else echo "pass $name produced no counters"; tail -5 $OUT/$name.log; fi
+  if [ -n "$f" ]; then python3 $ROOT/tools/pmc_report.py reduce $f $OUT/$name.csv $(live $OUT/$name.log) $(grep -o '"kernel_launches_per_diffusion_step": [0-9]*' $OUT/$name.log | grep -o '[0-9]*$'); else echo "pass $name produced no counters"; tail -5 $OUT/$name.log; fi
   rm -rf $OUT/raw_$name
 }
 BENCH_ARGS="$*"
@@ -20,7 +21,7 @@ BENCH_ARGS="$*"
 rm -rf $OUT/raw_trace
 timeout 900 rocprofv3 --kernel-trace --output-format csv -d $OUT/raw_trace -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --profile-steps $STEPS $BENCH_ARGS > $OUT/trace.log 2>&1
 f=$(find $OUT/raw_trace -name "*kernel_trace.csv" | head -1)
-python3 $ROOT/tools/pmc_report.py trace $f $OUT/trace.csv $STEPS $(grep -o '"kernel_launches_per_diffusion_step": [0-9]*' $OUT/trace.log | grep -o '[0-9]*$')
+python3 $ROOT/tools/pmc_report.py trace $f $OUT/trace.csv $(live $OUT/trace.log) $(grep -o '"kernel_launches_per_diffusion_step": [0-9]*' $OUT/trace.log | grep -o '[0-9]*$')
 rm -rf $OUT/raw_trace
 pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE
 pass sq2 SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_VMEM SQ_VALU_MFMA_COEXEC_CYCLES
@@ -28,5 +29,5 @@ pass fetch FETCH_SIZE TCC_HIT_sum
 pass write WRITE_SIZE TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum
 pass tcp TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
 HEAD=$(cd $ROOT && git rev-parse --short HEAD 2>/dev/null || echo unknown)
-python3 $ROOT/tools/pmc_report.py derive $OUT $OUT/summary.json "{\"tag\": \"$TAG\", \"bench_args\": \"$BENCH_ARGS\", \"tiles\": \"${FDM_TILE_OVERRIDE:-tuned per run}\", \"steps_profiled\": $STEPS}"
+python3 $ROOT/tools/pmc_report.py derive $OUT $OUT/summary.json "{\"tag\": \"$TAG\", \"bench_args\": \"$BENCH_ARGS\", \"tiles\": \"${FDM_TILE_OVERRIDE:-tuned per run}\", \"steps_profiled\": $(live $OUT/trace.log)}"
 ls $OUT
