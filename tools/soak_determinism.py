@@ -29,3 +29,24 @@ for preset, B, L, T, cfg, dt, reps in (("vocaset", 32, 200, 120, False, BF16, 4)
         if ref is None: ref = out.clone()
         assert torch.equal(out, ref), f"{preset} L={L} run {r} differs: max {float((out - ref).abs().max())}"
     print(f"{preset} B={B} S={S} L={L} T={T} cfg={cfg} { {BF16: 'bf16', F32: 'fp32', F16X3: 'f16x3'}[dt] }: {reps} runs bit-identical, tiles {plan.tiles}")
+
+# GEMM level: the one-round tiles (uneven LDS-DMA piece split, per-wave wait counts) against the 64x64 tile's bits, many launches
+import math
+from fdm_amd import ops
+from fdm_amd._lib import TILE_64x64, TILE_80x128, TILE_64x128
+g = torch.Generator().manual_seed(5)
+for dt, name in ((BF16, 'bf16'), (F16X3, 'f16x3'), (F32, 'fp32')):
+    for (M, N, K) in ((800, 3072, 1024), (800, 2048, 1024), (2400, 1536, 512), (815, 3072, 192)):
+        A = ops.to_operand(torch.randn(M, K, generator=g).to(DEV), dt)
+        Wt = ops.to_operand((torch.randn(N, K, generator=g) / math.sqrt(K)).to(DEV), dt)
+        ref = torch.zeros(M, N, device=DEV)
+        ops.gemm(A, Wt, M, N, K, out_f32=ref, tile=TILE_64x64)
+        out = torch.empty(M, N, device=DEV)
+        bad = 0
+        for tile in (TILE_80x128, TILE_64x128):
+            for rep in range(1500):
+                ops.gemm(A, Wt, M, N, K, out_f32=out, tile=tile)
+                if rep % 50 == 49 or rep < 3:
+                    bad += int(not torch.equal(out, ref))
+        assert bad == 0, f"{name} {(M, N, K)}: {bad} differing launches"
+    print(f"gemm one-round tiles {name}: 4 shapes x 2 tiles x 1500 launches, sampled compares all bit-identical")
