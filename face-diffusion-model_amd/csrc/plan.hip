@@ -14,9 +14,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <map>
 #include <string>
 #include <vector>
+
+#include <unistd.h>
 
 #include "../../include/fdm_hip.h"
 #include "common.hpp"
@@ -824,6 +827,67 @@ void apply_tile_override(std::map<std::string, int>& tiles) {      // FDM_TILE_O
   }
 }
 
+// ---- tuned tiles kept across processes (opt-in: FDM_TILE_CACHE=<file>).  One text line per (library version, arithmetic mode,
+// model geometry, shape): "<key>\t<site>=<tile>,...".  A plan whose shape is in the file takes the stored set at
+// fdm_audio_prepare without a single timing launch; fdm_plan_tune / the serving-time tuning of fdm_audio_prepare add their
+// result.  Written through a temporary file + rename: concurrent ranks may lose each other's additions, never corrupt the file.
+std::string store_key(const fdm_plan* P) {
+  const fdm_model_desc& m = P->m;
+  char b[160];
+  snprintf(b, sizeof(b), "v%d|dt%d|%d,%d,%d,%d,%d,%d,%d,%d|%s", fdm_version(), P->dtype, m.d, m.n_head, m.n_layers, m.ffn, m.G, m.c, m.audio_in, m.pair,
+           shape_key(P).c_str());
+  return b;
+}
+
+bool store_read(std::map<std::string, std::string>& lines) {
+  const char* path = getenv("FDM_TILE_CACHE");
+  if (!path || !*path) return false;
+  std::ifstream f(path);
+  std::string ln;
+  while (f && std::getline(f, ln)) {
+    const size_t tab = ln.find('\t');
+    if (tab != std::string::npos) lines[ln.substr(0, tab)] = ln.substr(tab + 1);
+  }
+  return true;
+}
+
+bool store_lookup(const fdm_plan* P, std::map<std::string, int>& tiles) {
+  std::map<std::string, std::string> lines;
+  if (!store_read(lines)) return false;
+  auto it = lines.find(store_key(P));
+  if (it == lines.end()) return false;
+  tiles.clear();
+  const std::string& v = it->second;
+  size_t pos = 0;
+  while (pos < v.size()) {
+    const size_t comma = v.find(',', pos), eq = v.find('=', pos);
+    const size_t end = comma == std::string::npos ? v.size() : comma;
+    if (eq != std::string::npos && eq < end) {
+      const int t = atoi(v.substr(eq + 1, end - eq - 1).c_str());
+      if (t < 0 || t > FDM_TILE_MAX) return false;      // a damaged line: tune again
+      if (t) tiles[v.substr(pos, eq - pos)] = t;
+    }
+    pos = end + 1;
+  }
+  return true;
+}
+
+void store_save(const fdm_plan* P, const std::map<std::string, int>& tiles) {
+  std::map<std::string, std::string> lines;
+  if (!store_read(lines)) return;
+  std::string v;
+  for (auto& kv : tiles)
+    if (kv.second) v += (v.empty() ? "" : ",") + kv.first + "=" + std::to_string(kv.second);
+  lines[store_key(P)] = v;
+  const std::string path = getenv("FDM_TILE_CACHE"), tmp = path + ".tmp" + std::to_string((long long)getpid());
+  {
+    std::ofstream f(tmp, std::ios::trunc);
+    if (!f) return;                                     // an unwritable location disables the store, never the plan
+    for (auto& kv : lines) f << kv.first << '\t' << kv.second << '\n';
+  }
+  if (rename(tmp.c_str(), path.c_str()) != 0) remove(tmp.c_str());
+}
+
 int tune_tiles_impl(fdm_plan* P, void* stream);
 
 // Time the candidate output tiles of every GEMM call site of the step at this plan's shapes and keep the fastest.  Cached per
@@ -841,6 +905,7 @@ int tune_tiles(fdm_plan* P, int force, void* stream) {
   const std::map<std::string, int> before = P->tiles;
   const int rc = tune_tiles_impl(P, stream);
   if (rc != FDM_OK) { P->tiles = before; (void)drop_programs(P, stream); }   // never leave a trial set behind
+  else store_save(P, P->tiles);
   return rc;
 }
 
@@ -1119,8 +1184,16 @@ int fdm_audio_prepare_conds(fdm_plan* P, const float* hub, int B0, int N, int fw
   P->prepared = true;
   auto it = P->tile_cache.find(shape_key(P));
   std::map<std::string, int> want;
-  if (it != P->tile_cache.end()) want = it->second;
-  else apply_tile_override(want);          // FDM_TILE_OVERRIDE pins tiles with or without the tuner (heuristic tiles elsewhere)
+  const char* tune_env = getenv("FDM_TUNE");
+  if (it != P->tile_cache.end()) {
+    want = it->second;
+  } else if (P->tune_enabled && !(tune_env && !strcmp(tune_env, "0")) && store_lookup(P, want)) {
+    apply_tile_override(want);             // a set tuned by an earlier process (FDM_TILE_CACHE): counts as tuned
+    P->tile_cache[shape_key(P)] = want;
+  } else {
+    want.clear();
+    apply_tile_override(want);             // FDM_TILE_OVERRIDE pins tiles with or without the tuner (heuristic tiles elsewhere)
+  }
   P->tiles = want;                          // (programs are keyed by the tile set they were recorded with)
   return tune_tiles(P, 0, stream);        // plan-time: only for a shape that has already served >= 2000 steps untuned
 }

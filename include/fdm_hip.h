@@ -392,7 +392,9 @@ int fdm_sample_graph(fdm_plan* p, const fdm_sample_args* a, void* stream);
 /* Plan-time tuning of the GEMM output tiles at the prepared shape (times candidates per call site; changes speed only, every
  * tile accumulates k in the same order).  Besides this call, fdm_audio_prepare tunes a shape that earlier sampling calls have
  * run >= 2000 diffusion steps at; fdm_sample_graph never tunes unless fdm_plan_set(p, "tune_lazy", 1).  FDM_TUNE=0 disables
- * the tuner; FDM_TILE_OVERRIDE="qkv=3,ffn1=2" pins call sites (applied at fdm_audio_prepare, with or without the tuner). */
+ * the tuner; FDM_TILE_OVERRIDE="qkv=3,ffn1=2" pins call sites (applied at fdm_audio_prepare, with or without the tuner).
+ * FDM_TILE_CACHE=<file> (opt-in) keeps tuned sets across processes: a tuning run appends "<version|mode|geometry|shape>\t<site>=<tile>,..."
+ * (temporary file + rename), and fdm_audio_prepare takes a stored set for its shape without any timing launch. */
 int fdm_plan_tune(fdm_plan* p, void* stream);
 /* Introspection / experiments: integer properties by name -- "launches_per_step", "graph_launches" (host graph launches of
  * the last fdm_sample_graph), "fuse_ln3", "rows", "tile.<call site>" (qkv, out, ffn1, ffn2, enc, dec, ...). */

@@ -472,6 +472,47 @@ def test_tile_override_applies_at_prepare_and_tuning_is_plan_time(monkeypatch):
     assert plan3.get("tuned") == 1                      # opted in: the third call (2000 steps seen) tuned in-call
 
 
+def test_tuned_tiles_persist_through_the_tile_cache_file(tmp_path, monkeypatch):
+    """FDM_TILE_CACHE=<file> (opt-in): fdm_plan_tune writes the shape's tile set (keyed by library version, arithmetic mode, model
+    geometry and shape); a NEW plan takes it at fdm_audio_prepare without tuning; another shape / mode / a damaged line does not
+    match; the file never changes results."""
+    path = tmp_path / "tiles.txt"
+    monkeypatch.setenv("FDM_TILE_CACHE", str(path))
+    w = W.make_fdm_weights("vocaset")
+    L = 200
+    inp = W.synth_inputs("vocaset", 4, L, seed=9)
+    a = DenoiserPlan("vocaset", w, BF16, DEV)
+    a.prepare(inp["hub"], inp["style"], L=L)
+    assert a.get("tuned") == 0 and not path.exists()
+    a.tune()
+    assert a.get("tuned") == 1
+    lines = path.read_text().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("v") and "\t" in lines[0]
+    ref = a.denoise(inp["x"].to(DEV), 500).clone()
+    b = DenoiserPlan("vocaset", w, BF16, DEV)
+    b.prepare(inp["hub"], inp["style"], L=L)
+    assert b.get("tuned") == 1 and b.tiles == a.tiles            # no fdm_plan_tune call on this plan
+    assert torch.equal(b.denoise(inp["x"].to(DEV), 500), ref)
+    b.prepare(inp["hub"][:2], inp["style"][:2], L=L)              # another shape: not in the file
+    assert b.get("tuned") == 0
+    c = DenoiserPlan("vocaset", w, F16X3, DEV)                    # another arithmetic mode: its own key
+    c.prepare(inp["hub"], inp["style"], L=L)
+    assert c.get("tuned") == 0
+    c.tune()
+    assert len(path.read_text().splitlines()) == 2
+    key = lines[0].split("\t")[0]
+    path.write_text(key + "\tqkv=99\n")                           # a damaged line is ignored (and replaced by the next tuning)
+    d = DenoiserPlan("vocaset", w, BF16, DEV)
+    d.prepare(inp["hub"], inp["style"], L=L)
+    assert d.get("tuned") == 0
+    assert torch.equal(d.denoise(inp["x"].to(DEV), 500), ref)
+    monkeypatch.setenv("FDM_TILE_CACHE", str(tmp_path / "no_such_dir" / "tiles.txt"))      # unwritable: the store is off, the plan works
+    e = DenoiserPlan("vocaset", w, BF16, DEV)
+    e.prepare(inp["hub"], inp["style"], L=L)
+    e.tune()
+    assert e.get("tuned") == 1 and torch.equal(e.denoise(inp["x"].to(DEV), 500), ref)
+
+
 def test_programs_are_kept_per_shape():
     """A serving loop that alternates between shapes finds its recorded programs again (keyed by shape and tile set) and gets the
     same bits as a fresh plan; a weight update still drops everything."""
