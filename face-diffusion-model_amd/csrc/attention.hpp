@@ -40,8 +40,10 @@ template <typename T> __device__ __forceinline__ float fexp(float x) {
 // key tile for the scores and once at the end for O); the probabilities are split the same way in registers.  fp32-class
 // results at a fifth of the fp32 kernel's MFMA time and half its key tiles.
 // Split kind at head_dim 256 (BIWI: 4 heads x 256): the fragments of a whole key tile (K 128 + V 128 registers) cannot be held
-// beside Q (64) and the two O^T accumulators (128), so K and V are STREAMED through the products -- K in two halves of the
-// head dim (the score accumulators carry across), V in two halves of the output rows -- at one wave per SIMD (~300 registers).
+// AT ONCE beside Q (64) and the two O^T accumulators (128), so they are held ONE AFTER THE OTHER at one wave per SIMD: the whole
+// K tile for the scores, then -- requested once the scores are done, its latency under the softmax arithmetic -- the whole V
+// tile into the registers K has freed (512 registers, no scratch).  Two dependent L2 round trips per key tile; streaming K and V
+// in halves (round 3's first form: four round trips, 463 registers) was 3.7 us slower per launch (cfg4 f16x3 0.826 -> 0.795 ms).
 template <typename T, int HD> constexpr bool attn_streamed() { return Opnd<T>::NP == 2 && HD == 256; }
 
 template <typename T, int HD, int QS>
@@ -58,9 +60,7 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   constexpr int NC = HD / 16;                  // 16-row chunks of O^T
   constexpr int BQ = 16 * QS;
   constexpr bool STREAM = attn_streamed<T, HD>();
-  constexpr int KSH = STREAM ? NKS / 2 : NKS;  // k-steps of K held at once
-  constexpr int NCH = STREAM ? NC / 2 : NC;    // O^T chunks whose V fragments are held at once
-  static_assert(!STREAM || QS == 1, "the streamed form runs one query sub-tile");
+  static_assert(!STREAM || QS == 1, "the K-then-V form runs one query sub-tile");
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, r16 = lane & 15;
@@ -123,54 +123,30 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   for (int kt = wave; kt < ntiles; kt += 4) {
     const int kbase = kt * KT;
     // fragment-packed K / V: every operand fragment of this key tile is one contiguous 1 KB run
-    u32x4 kcur[NSUB][KSH][NP];
-    auto load_k = [&](int ks0) {
+    u32x4 kcur[NSUB][NKS][NP];
 #pragma unroll
-      for (int s = 0; s < NSUB; ++s)
+    for (int s = 0; s < NSUB; ++s)
 #pragma unroll
-        for (int ks = 0; ks < KSH; ++ks)
+      for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-          for (int pl = 0; pl < NP; ++pl) kcur[s][ks][pl] = *(const u32x4*)(Kp + pl * kv_lo + (size_t)((kt * NSUB + s) * NKS + ks0 + ks) * (64 * EPC));
-    };
-    load_k(0);
-    u32x4 vf[NCH][NP];
-    auto load_v = [&](int c0, int c1, int cbase) {
+        for (int pl = 0; pl < NP; ++pl) kcur[s][ks][pl] = *(const u32x4*)(Kp + pl * kv_lo + (size_t)((kt * NSUB + s) * NKS + ks) * (64 * EPC));
+    u32x4 vf[NC][NP];
+    auto load_v = [&](int c0, int c1) {
 #pragma unroll
       for (int c = c0; c < c1; ++c)
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl) vf[c][pl] = *(const u32x4*)(Vp + pl * kv_lo + (size_t)(kt * NC + cbase + c) * (64 * EPC));
+        for (int pl = 0; pl < NP; ++pl) vf[c][pl] = *(const u32x4*)(Vp + pl * kv_lo + (size_t)(kt * NC + c) * (64 * EPC));
     };
-    // split kind: the second half of V is requested after the scores (into the registers the K fragments free), which
-    // keeps the kernel at two waves per SIMD; its latency overlaps the softmax arithmetic
+    // split kind: the second half of V (all of it at head_dim 256) is requested after the scores, into the registers the K
+    // fragments free, which keeps the kernel at two (one) waves per SIMD; its latency overlaps the softmax arithmetic
     constexpr int NC_EARLY = STREAM ? 0 : ((NP == 2) ? NC / 2 : NC);
-    load_v(0, NC_EARLY, 0);
+    load_v(0, NC_EARLY);
 #pragma unroll
     for (int u = 0; u < QS; ++u) {
       // a causal sub-tile whose last query precedes this key tile sees none of it (wave-uniform skip);
       // it also guarantees every processed tile starts at a key visible to all 16 queries (finite row maxima)
       if (p.causal && kbase > q0 + 16 * u + 15) continue;
       f32x4 sc[NSUB];
-      if constexpr (STREAM) {
-        // K streamed in two halves of the head dim; the score accumulators carry across
-        f32x4 a[NSUB], al[NSUB];
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s) { a[s] = f32x4{0.f, 0.f, 0.f, 0.f}; al[s] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int kh = 0; kh < NKS / KSH; ++kh) {
-          if (kh) load_k(kh * KSH);
-#pragma unroll
-          for (int s = 0; s < NSUB; ++s)
-#pragma unroll
-            for (int ks = 0; ks < KSH; ++ks) {
-              mma16<E>(a[s], kcur[s][ks][0], qf[u][kh * KSH + ks][0]);
-              mma16<E>(al[s], kcur[s][ks][0], qf[u][kh * KSH + ks][1]);
-              mma16<E>(al[s], kcur[s][ks][1], qf[u][kh * KSH + ks][0]);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < NSUB; ++s) sc[s] = a[s] + al[s] * (1.f / SCL);
-        load_v(0, NCH, 0);             // first half of V^T: its latency overlaps the softmax arithmetic
-      } else {
 #pragma unroll
       for (int s = 0; s < NSUB; ++s) {
         f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -189,8 +165,7 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
         }
         sc[s] = a;
       }
-      }
-      if constexpr (NP == 2 && QS == 1 && !STREAM) load_v(NC_EARLY, NC, 0);
+      if constexpr (NP == 2 && QS == 1) load_v(NC_EARLY, NC);
       // scores -> scaled, biased, masked.  This lane holds keys kbase + goff + j with j = 4s + r (j < 8), so with
       // D = qi - (kbase + goff):  floor((qi - kj) / period) = floor(D / period) - (j > D mod period)   (period >= 8)
       // -> one compare/select/fma per score instead of an int->float convert, floor and two multiplies.
@@ -269,7 +244,7 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
           pf = __builtin_bit_cast(u32x4, sc[0]);
         }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) Mma<T>::run(o[u][c], vf[c][0], pf);      // (NCH == NC for the one-plane kinds)
+        for (int c = 0; c < NC; ++c) Mma<T>::run(o[u][c], vf[c][0], pf);
       } else {
         typedef __attribute__((ext_vector_type(8))) E e8;
         e8 ph, plo;
@@ -282,14 +257,10 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
         }
         const u32x4 pfh = __builtin_bit_cast(u32x4, ph), pfl = __builtin_bit_cast(u32x4, plo);
 #pragma unroll
-        for (int ch = 0; ch < NC / NCH; ++ch) {
-          if (ch) load_v(0, NCH, ch * NCH);       // (streamed form: second half of the output rows)
-#pragma unroll
-          for (int c = 0; c < NCH; ++c) {
-            mma16<E>(o[u][ch * NCH + c], vf[c][0], pfh);
-            mma16<E>(ol[u][ch * NCH + c], vf[c][0], pfl);
-            mma16<E>(ol[u][ch * NCH + c], vf[c][1], pfh);
-          }
+        for (int c = 0; c < NC; ++c) {
+          mma16<E>(o[u][c], vf[c][0], pfh);
+          mma16<E>(ol[u][c], vf[c][0], pfl);
+          mma16<E>(ol[u][c], vf[c][1], pfh);
         }
       }
     }

@@ -155,7 +155,7 @@ def test_plan_layer_argument_validation_without_device():
     pd = _lib.ModelDesc()
     assert l.fdm_model_preset(b"biwi", C.byref(pd)) == 0 and pd.d // pd.n_head == 256
     p = C.c_void_p()
-    # geometry is checked before the device: head_dim 256 is valid in every mode (FDM_F16X3 streams K / V through the split attention kernel there), so on
+    # geometry is checked before the device: head_dim 256 is valid in every mode (FDM_F16X3 runs the one-wave-per-SIMD form of the split attention kernel there), so on
     # this box the call gets as far as "no device"; an unsupported head_dim is a shape error
     rc = l.fdm_plan_create(C.byref(pd), 1, 10, 0, _lib.F16X3, C.byref(p))
     assert (rc == -4 and b"no gfx950 device" in l.fdm_last_error()) or (rc == 0 and l.fdm_plan_destroy(p) == 0)

@@ -164,7 +164,7 @@ def test_long_chain_bf16_stays_close_to_fp32():
 def test_biwi_build_defined_semantics_vs_oracle(dtype):
     """BIWI denoiser (models/fdm.py is unrunnable as shipped): build-defined 'Dec' struct with the
     latent regrouped x8, style Mish, plain-Linear latent encoder, period-25 ALiBi.  Parity is pinned against the
-    oracle restatement only (NOT against the reference).  head_dim 256: the split mode runs the streamed form of the split attention
+    oracle restatement only (NOT against the reference).  head_dim 256: the split mode runs the K-then-V form of the split attention
     kernel (attention.hpp, attn_streamed; 58 launches per step like every other preset)."""
     preset = "biwi"
     w = W.make_fdm_weights(preset)

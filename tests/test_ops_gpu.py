@@ -325,8 +325,8 @@ def test_attention_via_qkv_gemm_layout(dtype, B, H, L, hd, causal, period):
 def test_split_attention_via_qkv_gemm(B, H, L, hd, causal, period):
     """FDM_F16X3: the QKV GEMM writes Q and the packed K / V as fp16 plane pairs, the split attention kernel runs both
     products in three 16-bit MFMA passes (probabilities split in registers) and writes O as a plane pair.  Checked against an
-    fp64 evaluation of the same fp32 inputs at the fp32 kernel's own tolerance.  head_dim 256 (BIWI) streams K and V through
-    the products at one wave per SIMD (attention.hpp, attn_streamed)."""
+    fp64 evaluation of the same fp32 inputs at the fp32 kernel's own tolerance.  head_dim 256 (BIWI) holds a key tile's K, then its V,
+    at one wave per SIMD (attention.hpp, attn_streamed)."""
     g = torch.Generator().manual_seed(L + hd)
     d = H * hd
     x = torch.randn(B * L, d, generator=g)
