@@ -1034,7 +1034,7 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
       FCK(chain_time(trial, &t_a));
       if (t_a < 0.997f * t_t) { tuned = trial; t_t = t_a; }
     }
-    if (t_t < 0.995f * t_h) keep = tuned;
+    if (t_t < 0.99f * t_h) keep = tuned;        // (below 1 % the chain timing's own spread decides: keep the heuristic set)
     if (getenv("FDM_TUNE_VERBOSE")) {
       std::string desc;
       for (auto& kv : tuned) desc += kv.first + "=" + std::to_string(kv.second) + ",";
