@@ -938,6 +938,12 @@ static int gemm_tile_override() {
 // 80x128 tiles that fill the chip in exactly one round (225..256 workgroups, e.g. 800 rows x 3072 columns = 240): every CU
 // streams one (80 + 128)-row operand pair instead of two or three 64x64 ones (12.7 vs 14.6 us bf16, 22.2 vs 28.4 us f16x3
 // on that shape; profiles/README.md round 3)
+static bool gemm_one_round(long long tiles) { return tiles > 192 && tiles <= 256; }
+// FDM_GEMM_RULES=0: the round-2 heuristic only (tile count thresholds), for A/B measurements of the round-3 rules
+static bool gemm_rules_on() {
+  static const bool v = [] { const char* e = getenv("FDM_GEMM_RULES"); return !(e && e[0] == '0'); }();
+  return v;
+}
 static bool gemm_one_round_80(const fdm_gemm_args& a) {
   const long long t80 = (long long)((a.M + 79) / 80) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
   return t80 > 224 && t80 <= 256 && (a.M % 80 == 0 || a.M % 80 > 40);   // (a mostly empty last row tile wastes the round)
@@ -976,6 +982,18 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   static const long long thr128x64 = [] { const char* e = getenv("FDM_GEMM_T128X64"); return e ? atoll(e) : 700LL; }();
   if (t128 >= thr128) return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
   if (gemm_one_round_80(a)) return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);
+  const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * batch;
+  // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two
+  //  64 KB rings per CU -- stay on it: MEAD's d = 512 sites at 1200-1600 rows lost 3-5 % on larger tiles)
+  if (gemm_rules_on() && sizeof(typename Opnd<T>::E) == 2 && a.M > 1024 && (t64 > 512 || a.K >= 1024)) {
+    // 1100..4000 rows (batched clips, long clips, CFG): what the plan-time tuner picks there (profiles/r3_tile_sweep/), as rules.
+    // A grid that fills the chip in exactly ONE round wins; else 128x64 -- on the 4-stage ring while its grid is one round, on the
+    // 3-stage ring (72 KB: two workgroups per CU, all of <= 512 tiles resident) beyond.
+    const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128) * batch;
+    if (gemm_one_round(t128)) return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);
+    if (gemm_one_round(t256)) return gemm_glds_launch_t<T, 256, 128, 4, 2, 3>(a, s);
+    if (t128x64 > 128) return t128x64 <= 256 ? gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s) : gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);
+  }
   if (t128x64 >= thr128x64) return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);  // 8 waves, 32x32 per wave
   return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                       // 8 waves, 32x16 per wave
 }
@@ -1009,6 +1027,17 @@ static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
     const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
     if (t128 >= 512) return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);
     if (gemm_one_round_80(a)) return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);
+    const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * batch;
+    if (!gemm_rules_on()) {
+    } else if (a.M > 1024) {            // the tuner's picks at 1100..4000 rows as rules (see gemm_dispatch)
+      if (gemm_one_round(t128)) return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);
+      if (t128x64 > 128 && t128x64 <= 256) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);     // (144 KB ring: one per CU, so one round only)
+    } else {
+      // a single short clip: 64x64 tiles leave half the CUs idle -> 32-row tiles (72 KB rings, two per CU); 257..512 tiles of a
+      // wide projection: the 2-stage ring (64 KB) keeps all of them resident in one round instead of two
+      if (t64 <= 128) return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);
+      if (t64 > 256 && t64 <= 512 && a.N >= 2048) return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);
+    }
     if (t128x64 >= 700) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);
     return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);
   }
