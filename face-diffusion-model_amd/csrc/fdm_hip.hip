@@ -152,6 +152,11 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
 }
 
+int fdm_gemm_heuristic_tile(const fdm_gemm_args* a) {
+  if (!a) return fail(FDM_ERR_ARG, "gemm_heuristic_tile: null argument");
+  return fdm::gemm_heuristic_tile_of(*a);
+}
+
 int fdm_op_attention(const fdm_attn_args* a, void* stream) {
   if (!a || !a->Q || !a->Kp || !a->Vp || !a->O) return fail(FDM_ERR_ARG, "attention: null operand");
   if (a->hd != 64 && a->hd != 128 && a->hd != 256) return fail(FDM_ERR_SHAPE, "attention: head_dim %d unsupported (64, 128, 256)", a->hd);

@@ -928,31 +928,75 @@ static hipError_t gemm_pp_launch_t(const fdm_gemm_args& a, hipStream_t s) {
   return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, false>(a, s);
 }
 
-// Tile choice: fdm_gemm_args.tile (the caller's plan-time choice), else the FDM_GEMM_TILE override (env, read once: the
-// FDM_TILE_* value forced for every GEMM, for A/B measurements), else a heuristic on the tile count.
+// ---- tile choice -------------------------------------------------------------------------------------------------------
+// fdm_gemm_args.tile (the caller's plan-time choice), else the FDM_GEMM_TILE override (env, read once: the FDM_TILE_* value
+// forced for every GEMM, for A/B measurements), else the heuristic below: gemm_heuristic_tile names the FDM_TILE_* a launch
+// with tile = 0 resolves to (also exported as fdm_gemm_heuristic_tile, so that the plan-time tuner does not time a candidate
+// against itself).  Every tile accumulates k in the same order: the choice changes speed, never results.
 static int gemm_tile_override() {
   static int v = [] { const char* e = getenv("FDM_GEMM_TILE"); return e ? atoi(e) : 0; }();
   return v;
 }
-
-// 80x128 tiles that fill the chip in exactly one round (225..256 workgroups, e.g. 800 rows x 3072 columns = 240): every CU
-// streams one (80 + 128)-row operand pair instead of two or three 64x64 ones (12.7 vs 14.6 us bf16, 22.2 vs 28.4 us f16x3
-// on that shape; profiles/README.md round 3)
 static bool gemm_one_round(long long tiles) { return tiles > 192 && tiles <= 256; }
 // FDM_GEMM_RULES=0: the round-2 heuristic only (tile count thresholds), for A/B measurements of the round-3 rules
 static bool gemm_rules_on() {
   static const bool v = [] { const char* e = getenv("FDM_GEMM_RULES"); return !(e && e[0] == '0'); }();
   return v;
 }
+// 80x128 tiles that fill the chip in exactly one round (225..256 workgroups, e.g. 800 rows x 3072 columns = 240): every CU
+// streams one (80 + 128)-row operand pair instead of two or three 64x64 ones (12.7 vs 14.6 us bf16, 22.2 vs 28.4 us f16x3
+// on that shape; profiles/README.md round 3)
 static bool gemm_one_round_80(const fdm_gemm_args& a) {
   const long long t80 = (long long)((a.M + 79) / 80) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
   return t80 > 224 && t80 <= 256 && (a.M % 80 == 0 || a.M % 80 > 40);   // (a mostly empty last row tile wastes the round)
 }
 
-template <typename T>
-static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
+// elem_bytes: 4 (fp32) or 2; split: the two-plane kinds (a ring stage is twice as large there, so their tile set is the part
+// of the one-plane set whose ring fits 160 KB of LDS)
+static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool split) {
   const long long batch = a.batch > 0 ? a.batch : 1;
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
+  const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
+  const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * batch;
+  if (!split) {
+    // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;
+    // below that the 64x64 tile's extra blocks beat its higher L2->LDS traffic.
+    static const long long thr128 = [] { const char* e = getenv("FDM_GEMM_T128"); return e ? atoll(e) : 512LL; }();
+    static const long long thr128x64 = [] { const char* e = getenv("FDM_GEMM_T128X64"); return e ? atoll(e) : 700LL; }();
+    if (t128 >= thr128) return FDM_TILE_128x128;
+    if (gemm_one_round_80(a)) return FDM_TILE_80x128;
+    // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two
+    //  64 KB rings per CU -- stay on it: MEAD's d = 512 sites at 1200-1600 rows lost 3-5 % on larger tiles)
+    if (gemm_rules_on() && elem_bytes == 2 && a.M > 1024 && (t64 > 512 || a.K >= 1024)) {
+      // 1100..4000 rows (batched clips, long clips, CFG): what the plan-time tuner picks there (profiles/r3_tile_sweep/), as rules.
+      // A grid that fills the chip in exactly ONE round wins; else 128x64 -- on the 4-stage ring while its grid is one round, on the
+      // 3-stage ring (72 KB: two workgroups per CU, all of <= 512 tiles resident) beyond.
+      const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128) * batch;
+      if (gemm_one_round(t128)) return FDM_TILE_128x128;
+      if (gemm_one_round(t256)) return FDM_TILE_256x128;
+      if (t128x64 > 128) return t128x64 <= 256 ? FDM_TILE_128x64 : FDM_TILE_128x64_S3;
+    }
+    if (t128x64 >= thr128x64) return FDM_TILE_128x64;
+    return FDM_TILE_64x64;
+  }
+  if (t128 >= 512) return FDM_TILE_128x128;
+  if (gemm_one_round_80(a)) return FDM_TILE_80x128;
+  if (!gemm_rules_on()) {
+  } else if (a.M > 1024) {            // the tuner's picks at 1100..4000 rows as rules (see above)
+    if (gemm_one_round(t128)) return FDM_TILE_128x128;
+    if (t128x64 > 128 && t128x64 <= 256) return FDM_TILE_128x64_S3;     // (144 KB ring: one per CU, so one round only)
+  } else {
+    // a single short clip: 64x64 tiles leave half the CUs idle -> 32-row tiles (72 KB rings, two per CU); 257..512 tiles of a
+    // wide projection: the 2-stage ring (64 KB) keeps all of them resident in one round instead of two
+    if (t64 <= 128) return FDM_TILE_32x64_S3;
+    if (t64 > 256 && t64 <= 512 && a.N >= 2048) return FDM_TILE_64x64_S2;
+  }
+  if (t128x64 >= 700) return FDM_TILE_128x64_S3;
+  return FDM_TILE_64x64;
+}
+
+template <typename T>
+static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   if (a.sched_fuse) {     // (validated: interior tiles only -> the lean epilogue)
     // thousands of rows: the scheduler-fused latent decoder on the ping-pong tile when the plan's tuner picked it
     if (a.tile == FDM_TILE_256x128_PP && !a.ln_stat_in && a.N % 128 == 0)
@@ -960,8 +1004,8 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
                         : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
   }
-  switch (a.tile > 0 ? a.tile : gemm_tile_override()) {
-    case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);      // 8 waves, 32x16 per wave
+  const int want = a.tile > 0 ? a.tile : gemm_tile_override();
+  switch (want > 0 ? want : gemm_heuristic_tile(a, (int)sizeof(typename Opnd<T>::E), false)) {
     case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
     case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);  // 8 waves, 64x32 per wave
     case FDM_TILE_96x128: return gemm_glds_launch_t<T, 96, 128, 2, 2, 4>(a, s);    // 4 waves, 48x64 per wave
@@ -973,44 +1017,22 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_256x128_PP: return gemm_pp_launch_t<T, 256, 128, 4, 2, 3>(a, s);   // ping-pong loop, 64x64 per wave, 146 KB
     case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);      // 8 waves, 80x16 per wave: 800 rows x 3072 = 240 workgroups
     case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4>(a, s);      // 8 waves, 32x32 per wave
-    default: break;
+    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                    // FDM_TILE_64x64: 8 waves, 32x16 per wave
   }
-  // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;
-  // below that the 64x64 tile's extra blocks beat its higher L2->LDS traffic.
-  const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
-  static const long long thr128 = [] { const char* e = getenv("FDM_GEMM_T128"); return e ? atoll(e) : 512LL; }();
-  static const long long thr128x64 = [] { const char* e = getenv("FDM_GEMM_T128X64"); return e ? atoll(e) : 700LL; }();
-  if (t128 >= thr128) return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);   // 8 waves, 64x32 per wave
-  if (gemm_one_round_80(a)) return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);
-  const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * batch;
-  // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two
-  //  64 KB rings per CU -- stay on it: MEAD's d = 512 sites at 1200-1600 rows lost 3-5 % on larger tiles)
-  if (gemm_rules_on() && sizeof(typename Opnd<T>::E) == 2 && a.M > 1024 && (t64 > 512 || a.K >= 1024)) {
-    // 1100..4000 rows (batched clips, long clips, CFG): what the plan-time tuner picks there (profiles/r3_tile_sweep/), as rules.
-    // A grid that fills the chip in exactly ONE round wins; else 128x64 -- on the 4-stage ring while its grid is one round, on the
-    // 3-stage ring (72 KB: two workgroups per CU, all of <= 512 tiles resident) beyond.
-    const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128) * batch;
-    if (gemm_one_round(t128)) return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);
-    if (gemm_one_round(t256)) return gemm_glds_launch_t<T, 256, 128, 4, 2, 3>(a, s);
-    if (t128x64 > 128) return t128x64 <= 256 ? gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s) : gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);
-  }
-  if (t128x64 >= thr128x64) return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);  // 8 waves, 32x32 per wave
-  return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                       // 8 waves, 32x16 per wave
 }
 
 // Split kinds: a ring stage is twice as large (hi and lo planes of both operands), so the tile set is the part of the
 // one above whose ring fits 160 KB of LDS; other FDM_TILE_* values map to the nearest member.
 template <typename T>
 static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
-  const long long batch = a.batch > 0 ? a.batch : 1;
   if (a.sched_fuse)
     return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
                         : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
   if constexpr (std::is_same<T, bf16x3_t>::value) {
     return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                          // comparison mode: one tile
   } else {
-    switch (a.tile > 0 ? a.tile : gemm_tile_override()) {
-      case FDM_TILE_64x64: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);     // 128 KB ring
+    const int want = a.tile > 0 ? a.tile : gemm_tile_override();
+    switch (want > 0 ? want : gemm_heuristic_tile(a, 2, true)) {
       case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);  // 96 KB
       case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);  // 64 KB -> 2 workgroups per CU
       case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
@@ -1018,28 +1040,12 @@ static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
       case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);   // 144 KB
       case FDM_TILE_128x128:
       case FDM_TILE_96x128:
-      case FDM_TILE_256x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);    // 128 KB, one tile in flight
+      case FDM_TILE_256x128:
+      case FDM_TILE_256x128_PP: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);    // 128 KB, one tile in flight
       case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);      // 156 KB
       case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 3>(a, s);      // 144 KB
-      default: break;
+      default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                    // FDM_TILE_64x64: 128 KB ring
     }
-    const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
-    const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
-    if (t128 >= 512) return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);
-    if (gemm_one_round_80(a)) return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);
-    const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * batch;
-    if (!gemm_rules_on()) {
-    } else if (a.M > 1024) {            // the tuner's picks at 1100..4000 rows as rules (see gemm_dispatch)
-      if (gemm_one_round(t128)) return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);
-      if (t128x64 > 128 && t128x64 <= 256) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);     // (144 KB ring: one per CU, so one round only)
-    } else {
-      // a single short clip: 64x64 tiles leave half the CUs idle -> 32-row tiles (72 KB rings, two per CU); 257..512 tiles of a
-      // wide projection: the 2-stage ring (64 KB) keeps all of them resident in one round instead of two
-      if (t64 <= 128) return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);
-      if (t64 > 256 && t64 <= 512 && a.N >= 2048) return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);
-    }
-    if (t128x64 >= 700) return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);
-    return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);
   }
 }
 

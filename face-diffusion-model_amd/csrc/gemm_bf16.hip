@@ -2,3 +2,12 @@
 #include "gemm.hpp"
 #include "kernels.hpp"
 namespace fdm { hipError_t gemm_launch_bf16(const fdm_gemm_args& a, hipStream_t s) { return gemm_dispatch<bf16>(a, s); } }
+// the FDM_TILE_* a launch with tile = 0 resolves to, for every operand kind (include/fdm_hip.h: fdm_gemm_heuristic_tile)
+namespace fdm {
+int gemm_heuristic_tile_of(const fdm_gemm_args& a) {
+  if (a.sched_fuse || a.dtype == FDM_BF16X3) return FDM_TILE_64x64;
+  const int want = gemm_tile_override();
+  if (want > 0) return want;
+  return gemm_heuristic_tile(a, a.dtype == FDM_F32 ? 4 : 2, a.dtype == FDM_F16X3);
+}
+}

@@ -80,6 +80,7 @@ SYMBOLS = {
     "fdm_abi_struct_size": (ci, [C.c_char_p]),
     "fdm_device_ok": (ci, []),
     "fdm_op_gemm": (ci, [C.POINTER(GemmArgs), vp]),
+    "fdm_gemm_heuristic_tile": (ci, [C.POINTER(GemmArgs)]),
     "fdm_op_attention": (ci, [C.POINTER(AttnArgs), vp]),
     "fdm_op_pack_kv": (ci, [vp, ll, vp, ll, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "fdm_op_layernorm": (ci, [C.POINTER(LnArgs), vp]),

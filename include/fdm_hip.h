@@ -169,6 +169,9 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_64x128 12     /* 64x128: 13 row tiles for 800 rows -> 208 workgroups at N = 2048 in one round (FFN1 in the split modes) */
 #define FDM_TILE_MAX 12
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
+/* The FDM_TILE_* value a launch of *a with tile = 0 resolves to (the library heuristic on M, N, K, batch and the operand kind;
+ * no device work, a->tile is ignored).  The plan-time tuner uses it to leave the heuristic's own tile out of its candidates. */
+int fdm_gemm_heuristic_tile(const fdm_gemm_args* a);
 
 /* ------------------------------------------------------------------------------------------
  * Fused softmax(Q K^T * scale + bias) V for one [B, H, L, hd] problem.

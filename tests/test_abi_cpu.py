@@ -161,3 +161,35 @@ def test_plan_layer_argument_validation_without_device():
     assert (rc == -4 and b"no gfx950 device" in l.fdm_last_error()) or (rc == 0 and l.fdm_plan_destroy(p) == 0)
     pd.n_head = 32
     assert l.fdm_plan_create(C.byref(pd), 1, 10, 0, _lib.F16X3, C.byref(p)) == -2 and b"head_dim" in l.fdm_last_error()
+
+
+def test_tile_heuristic_is_a_pure_function_of_the_shape():
+    """fdm_gemm_heuristic_tile (host only): the FDM_TILE_* a launch with tile = 0 resolves to.  Pins the rules the round-3 sweep
+    derived (profiles/r3_tile_sweep/): one-round grids (80x128 at 800 x 3072, 128x128 at 1992 x 2048, 256x128 at 2400 x 3072),
+    128x64 rings above 1024 rows, 64x64 for the step's N = 1024 sites at 800 rows, short clips in the split kind on 32-row tiles;
+    the fp32 kind keeps the round-2 thresholds."""
+    from fdm_amd import _lib
+    l = _lib.lib()
+
+    def tile(dtype, M, N, K, batch=0, sched_fuse=0):
+        a = _lib.GemmArgs()
+        a.M, a.N, a.K, a.dtype, a.batch, a.sched_fuse = M, N, K, dtype, batch, sched_fuse
+        a.tile = 7                      # ignored by the query
+        return l.fdm_gemm_heuristic_tile(C.byref(a))
+
+    assert l.fdm_gemm_heuristic_tile(None) == -1
+    B, F, S = _lib.BF16, _lib.F32, _lib.F16X3
+    assert tile(B, 800, 3072, 1024) == _lib.TILE_80x128 and tile(S, 800, 3072, 1024) == _lib.TILE_80x128 and tile(F, 800, 3072, 1024) == _lib.TILE_80x128
+    assert tile(B, 800, 1024, 1024) == _lib.TILE_64x64 and tile(B, 800, 1024, 2048) == _lib.TILE_64x64 and tile(B, 800, 2048, 1024) == _lib.TILE_64x64
+    assert tile(B, 100, 1024, 1024) == _lib.TILE_64x64 and tile(S, 100, 1024, 1024) == _lib.TILE_32x64_S3
+    assert tile(S, 600, 3072, 1024) == _lib.TILE_64x64_S2 and tile(S, 800, 1024, 1024) == _lib.TILE_64x64
+    assert tile(B, 1992, 2048, 1024) == _lib.TILE_128x128 and tile(S, 1992, 2048, 1024) == _lib.TILE_128x128      # 16 x 16 = 256 tiles
+    assert tile(B, 2400, 3072, 1024) == _lib.TILE_256x128                                                         # 10 x 24 = 240 tiles
+    assert tile(B, 1200, 1024, 1024) == _lib.TILE_128x64 and tile(B, 3000, 1024, 1024) == _lib.TILE_128x64_S3 and tile(B, 3200, 1024, 1024) == _lib.TILE_128x128
+    assert tile(S, 1200, 1024, 1024) == _lib.TILE_128x64_S3 and tile(S, 2400, 2048, 1024) == _lib.TILE_64x64
+    assert tile(B, 1200, 512, 512) == _lib.TILE_64x64                   # MEAD's short-K sites stay on the resident 64x64 grid
+    assert tile(F, 1992, 2048, 1024) == _lib.TILE_64x64 and tile(F, 1200, 1024, 1024) == _lib.TILE_64x64
+    assert tile(B, 6400, 3072, 1024) == _lib.TILE_128x128 and tile(S, 6400, 1024, 2048) == _lib.TILE_128x64_S3
+    assert tile(B, 2400, 1024, 1024) == _lib.TILE_80x128                # 30 x 8 = 240 tiles
+    assert tile(B, 800, 1024, 1024, sched_fuse=1) == _lib.TILE_64x64 and tile(_lib.BF16X3, 1992, 2048, 1024) == _lib.TILE_64x64
+    assert tile(B, 100, 1024, 1024, batch=8) == _lib.TILE_64x64
