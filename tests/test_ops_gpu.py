@@ -188,6 +188,34 @@ def test_one_round_tiles_are_bit_identical(dtype):
             assert torch.equal(a_, b_)
 
 
+@pytest.mark.parametrize("dtype", [BF16, F32, F16X3])
+def test_every_tile_on_random_ragged_shapes(dtype):
+    """All twelve FDM_TILE_* ids on 20 seeded random shapes (rows and columns that are not tile multiples, K from one k-tile up,
+    random activation, with / without residual and bias): the general (edge-handling) epilogue of every tile gives the bits of
+    the 64x64 tile, and those are within the kind's tolerance of an fp64 product."""
+    import random
+    rnd = random.Random(1234 + dtype)
+    g = torch.Generator().manual_seed(99)
+    k_unit = 32 if dtype == F32 else 64
+    acts = [ACT_NONE, ACT_RELU, ACT_GELU_ERF, ACT_MISH, ACT_LEAKY02]
+    for case in range(20):
+        M, N, K = rnd.randint(1, 700), rnd.choice([rnd.randint(1, 90) * 4, rnd.randint(1, 12) * 128]), k_unit * rnd.randint(1, 9)
+        act, use_res, use_bias = rnd.choice(acts), rnd.random() < 0.5, rnd.random() < 0.7
+        A32 = torch.randn(M, K, generator=g)
+        W32 = torch.randn(N, K, generator=g) / math.sqrt(K)
+        A, W = ops.to_operand(A32.to(DEV), dtype), ops.to_operand(W32.to(DEV), dtype)
+        bias = torch.randn(N, generator=g).to(DEV) if use_bias else None
+        res = torch.randn(M, N, generator=g).to(DEV) if use_res else None
+        ref = torch.zeros(M, N, device=DEV)
+        ops.gemm(A, W, M, N, K, bias=bias, act=act, resid=res, out_f32=ref, tile=1)
+        want = act_ref(A32.double() @ W32.double().t() + (bias.cpu().double() if use_bias else 0.0), act) + (res.cpu().double() if use_res else 0.0)
+        assert rel(ref, want) < (2e-2 if dtype == BF16 else 2e-5), f"case {case}: {(M, N, K)} act {act}"
+        for tile in range(2, 13):
+            out = torch.full((M, N), float("nan"), device=DEV)
+            ops.gemm(A, W, M, N, K, bias=bias, act=act, resid=res, out_f32=out, tile=tile)
+            assert torch.equal(out, ref), f"case {case}: tile {tile} shape {(M, N, K)} act {act} res {use_res} bias {use_bias}"
+
+
 def test_split_producers_write_plane_pairs():
     """LayerNorm, scheduler and fp32 attention write GEMM inputs as plane pairs in the split modes."""
     g = torch.Generator().manual_seed(3)
