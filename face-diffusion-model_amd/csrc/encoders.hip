@@ -85,7 +85,7 @@ __global__ void argmax_rows_kernel(const float* x, int* out, int B, int n) {
 
 // ---- shared bookkeeping -----------------------------------------------------------------------------------------------
 struct Wt { float* p = nullptr; long long n = 0; };
-struct Mat { void* p = nullptr; };      // operand-kind matrix (fp32 or bf16: the once-per-clip stages have no split mode)
+struct Mat { void* p = nullptr; long long lo = 0; };      // operand-kind matrix; lo = elements between the hi and lo planes (split kind)
 
 struct Arena {
   std::vector<void*> allocs;
@@ -120,11 +120,12 @@ struct Store {       // fp32 weights by reference state-dict name (plan-owned co
   }
 };
 
-size_t esize(int dtype) { return dtype == FDM_BF16 ? 2 : 4; }
+size_t esize(int dtype) { return dtype == FDM_BF16 ? 2 : 4; }      // (FDM_F16X3: two 2-byte planes = 4)
 
 int to_operand(Arena& mem, int dtype, const float* src, long long n, Mat* out, void* stream) {
   if (dtype == FDM_F32) { out->p = (void*)src; return FDM_OK; }
-  FCK(mem.alloc(&out->p, (size_t)n * 2));
+  FCK(mem.alloc(&out->p, (size_t)n * esize(dtype)));
+  out->lo = dtype == FDM_F16X3 ? n : 0;          // fdm_op_cast writes the lo plane n elements after the hi plane
   return fdm_op_cast(src, out->p, n, dtype, stream);
 }
 
@@ -160,6 +161,9 @@ const int CD = 512, POS_K = 128, POS_G = 16;
 // =====================================================================================================================
 struct fdm_audio_encoder {
   int kind = 0, n_layers = 0, dtype = FDM_F32;
+  // FDM_F16X3: the transformer layers (84 % of the FLOPs) run on split-fp16 operands, the front (conv stack, projection,
+  // positional conv) stays fp32 -- fp32-class features at well under half the fp32 encoder's time
+  int front_dtype() const { return dtype == FDM_F16X3 ? FDM_F32 : dtype; }
   int D = 1024, H = 16, FFN = 4096;
   bool conv_layer_norm = true, conv_bias = true, stable_ln = true;
   Store st;
@@ -187,7 +191,7 @@ void conv_lengths(int n, int* T) {
 int enc_commit(fdm_audio_encoder* E, void* stream) {
   if (E->committed) return FDM_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int D = E->D, dt = E->dtype;
+  const int D = E->D, dt = E->front_dtype(), dtl = E->dtype;
   Store& st = E->st;
   const float* p = nullptr;
   for (int i = 0; i < 7; ++i) {
@@ -251,18 +255,18 @@ int enc_commit(fdm_audio_encoder* E, void* stream) {
       HIPCK(hipMemcpyAsync(wqkv + (size_t)j * D * D, w, (size_t)D * D * 4, hipMemcpyDeviceToDevice, s));
       HIPCK(hipMemcpyAsync(bqkv + (size_t)j * D, b, (size_t)D * 4, hipMemcpyDeviceToDevice, s));
     }
-    FCK(to_operand(E->mem, dt, wqkv, 3LL * D * D, &ly.wqkv, stream));
+    FCK(to_operand(E->mem, dtl, wqkv, 3LL * D * D, &ly.wqkv, stream));
     ly.bqkv = bqkv;
     FCK(st.need(P + "attention.out_proj.weight", (long long)D * D, &p));
-    FCK(to_operand(E->mem, dt, p, (long long)D * D, &ly.wo, stream));
+    FCK(to_operand(E->mem, dtl, p, (long long)D * D, &ly.wo, stream));
     FCK(st.need(P + "attention.out_proj.bias", D, &ly.bo));
     FCK(st.need(P + "layer_norm.weight", D, &ly.ln1g)); FCK(st.need(P + "layer_norm.bias", D, &ly.ln1b));
     FCK(st.need(P + "final_layer_norm.weight", D, &ly.ln2g)); FCK(st.need(P + "final_layer_norm.bias", D, &ly.ln2b));
     FCK(st.need(P + "feed_forward.intermediate_dense.weight", (long long)E->FFN * D, &p));
-    FCK(to_operand(E->mem, dt, p, (long long)E->FFN * D, &ly.w1, stream));
+    FCK(to_operand(E->mem, dtl, p, (long long)E->FFN * D, &ly.w1, stream));
     FCK(st.need(P + "feed_forward.intermediate_dense.bias", E->FFN, &ly.b1));
     FCK(st.need(P + "feed_forward.output_dense.weight", (long long)D * E->FFN, &p));
-    FCK(to_operand(E->mem, dt, p, (long long)D * E->FFN, &ly.w2, stream));
+    FCK(to_operand(E->mem, dtl, p, (long long)D * E->FFN, &ly.w2, stream));
     FCK(st.need(P + "feed_forward.output_dense.bias", D, &ly.b2));
   }
   FCK(st.need("encoder.layer_norm.weight", D, &E->fin_g));
@@ -279,16 +283,16 @@ int enc_reserve(fdm_audio_encoder* E, int B, int n) {
   E->ws.release();
   int T[7];
   conv_lengths(n, T);
-  const size_t es = esize(E->dtype), D = E->D;
+  const size_t es = esize(E->front_dtype()), esl = esize(E->dtype), D = E->D;
   const size_t r0 = (size_t)B * T[0], N = (size_t)T[6] + 2, M = (size_t)B * N;
   FCK(E->ws.alloc_t(&E->x32, r0 * CD)); FCK(E->ws.alloc_t(&E->y32, (size_t)B * T[1] * CD));
   FCK(E->ws.alloc(&E->xa, r0 * CD * es)); FCK(E->ws.alloc(&E->xb, (size_t)B * T[1] * CD * es));
   FCK(E->ws.alloc_t(&E->g6, M * CD)); FCK(E->ws.alloc_t(&E->gi, M * CD)); FCK(E->ws.alloc(&E->ft, M * CD * es));
   FCK(E->ws.alloc_t(&E->h, M * D)); FCK(E->ws.alloc_t(&E->h2, M * D)); FCK(E->ws.alloc_t(&E->hb, M * D)); FCK(E->ws.alloc_t(&E->x1, M * D));
-  FCK(E->ws.alloc(&E->ht, M * D * es)); FCK(E->ws.alloc(&E->xt, M * D * es)); FCK(E->ws.alloc(&E->q, M * D * es)); FCK(E->ws.alloc(&E->ctx, M * D * es));
+  FCK(E->ws.alloc(&E->ht, M * D * es)); FCK(E->ws.alloc(&E->xt, M * D * esl)); FCK(E->ws.alloc(&E->q, M * D * esl)); FCK(E->ws.alloc(&E->ctx, M * D * esl));
   FCK(E->ws.alloc(&E->xg, (size_t)POS_G * B * (N + POS_K) * (D / POS_G) * es));
-  FCK(E->ws.alloc(&E->u, M * E->FFN * es));
-  FCK(E->ws.alloc(&E->kp, (size_t)B * kv_pad((int)N) * D * es, true)); FCK(E->ws.alloc(&E->vp, (size_t)B * kv_pad((int)N) * D * es, true));
+  FCK(E->ws.alloc(&E->u, M * E->FFN * esl));
+  FCK(E->ws.alloc(&E->kp, (size_t)B * kv_pad((int)N) * D * esl, true)); FCK(E->ws.alloc(&E->vp, (size_t)B * kv_pad((int)N) * D * esl, true));
   E->capB = B; E->capN = n;
   return FDM_OK;
 }
@@ -307,7 +311,8 @@ int fdm_hubert_frames(int n_samples) {
 int fdm_hubert_create(int kind, int n_layers, int dtype, fdm_audio_encoder** out) {
   if (!out) return fail(FDM_ERR_ARG, "hubert_create: null out");
   if (kind != 0 && kind != 1) return fail(FDM_ERR_ARG, "hubert_create: kind %d (0 = HuBERT-large, 1 = wav2vec2-base)", kind);
-  if (dtype != FDM_F32 && dtype != FDM_BF16) return fail(FDM_ERR_ARG, "hubert_create: dtype %d (the once-per-clip stages run in fp32 or bf16)", dtype);
+  if (dtype != FDM_F32 && dtype != FDM_BF16 && dtype != FDM_F16X3)
+    return fail(FDM_ERR_ARG, "hubert_create: dtype %d (fp32, bf16, or FDM_F16X3 = split-fp16 transformer layers behind an fp32 front)", dtype);
   fdm_audio_encoder* E = new (std::nothrow) fdm_audio_encoder();
   if (!E) return fail(FDM_ERR_STATE, "hubert_create: out of memory");
   E->kind = kind; E->dtype = dtype;
@@ -351,8 +356,9 @@ int fdm_hubert_forward(fdm_audio_encoder* E, const float* wav, int B, int n, int
   }
   FCK(enc_commit(E, stream));
   FCK(enc_reserve(E, B, n));
-  const int D = E->D, dt = E->dtype, H = E->H, FFN = E->FFN, HD = 64;
-  const size_t es = esize(dt);
+  const int D = E->D, dt = E->front_dtype(), dtl = E->dtype, H = E->H, FFN = E->FFN, HD = 64;
+  const size_t es = esize(dt), esl = esize(dtl);
+  const bool split = dtl == FDM_F16X3;
   // --- conv feature extractor (channels-last) ---
   FCK(fdm_op_conv0(wav, E->conv0_w, E->conv_b[0], E->x32, B, n, T[0], stream));
   void* xt = E->xa;
@@ -401,57 +407,72 @@ int fdm_hubert_forward(fdm_audio_encoder* E, const float* wav, int B, int n, int
   float* hx = E->h;         // free fp32 buffer (the pre-posconv h)
   // --- encoder layers ---
   const int Lpad = kv_pad(N);
-  HIPCK(hipMemsetAsync(E->kp, 0, (size_t)B * Lpad * D * es, (hipStream_t)stream));       // pad keys must be finite; the layout depends on N
-  HIPCK(hipMemsetAsync(E->vp, 0, (size_t)B * Lpad * D * es, (hipStream_t)stream));
+  HIPCK(hipMemsetAsync(E->kp, 0, (size_t)B * Lpad * D * esl, (hipStream_t)stream));       // pad keys must be finite; the layout depends on N
+  HIPCK(hipMemsetAsync(E->vp, 0, (size_t)B * Lpad * D * esl, (hipStream_t)stream));
+  // split kind: every operand of the layer loop is a plane pair; lo planes sit one whole matrix after the hi planes
+  const long long lo_md = split ? (long long)M * D : 0, lo_mf = split ? (long long)M * FFN : 0, lo_kv = split ? (long long)B * Lpad * D : 0;
+  auto lgemm = [&](const void* A, long long a_lo, const Mat& W, int n_out, int k_in) {
+    fdm_gemm_args a = gemm_args(dtl, A, W.p, M, n_out, k_in);
+    a.a_lo_off = a_lo; a.w_lo_off = W.lo;
+    return a;
+  };
+  auto lnorm = [&](const float* x, const float* gam, const float* bet, float* y32, void* yt) {
+    fdm_ln_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.M = M; a.d = D; a.gamma = gam; a.beta = bet; a.eps = 1e-5f; a.act = FDM_ACT_NONE; a.y_f32 = y32; a.y_t = yt; a.dtype = dtl;
+    a.y_t_lo_off = yt ? lo_md : 0;
+    return fdm_op_layernorm(&a, stream);
+  };
   auto qkv = [&](const void* a_in, const Layer& ly) {
-    fdm_gemm_args a = gemm_args(dt, a_in, ly.wqkv.p, M, 3 * D, D);
-    a.bias = ly.bqkv; a.out_t = E->q; a.ldo_t = D; a.out_kp = E->kp; a.kp_col0 = D; a.out_vp = E->vp; a.vp_col0 = 2 * D;
-    a.kv_L = N; a.kv_Lpad = Lpad; a.kv_hd = HD;
+    fdm_gemm_args a = lgemm(a_in, lo_md, ly.wqkv, 3 * D, D);
+    a.bias = ly.bqkv; a.out_t = E->q; a.ldo_t = D; a.out_t_lo_off = lo_md; a.out_kp = E->kp; a.kp_col0 = D; a.out_vp = E->vp; a.vp_col0 = 2 * D;
+    a.kv_L = N; a.kv_Lpad = Lpad; a.kv_hd = HD; a.kv_lo_off = lo_kv;
     return fdm_op_gemm(&a, stream);
   };
   auto attn = [&]() {
     fdm_attn_args a;
     memset(&a, 0, sizeof(a));
     a.Q = E->q; a.ldq = D; a.Kp = E->kp; a.Vp = E->vp; a.Lpad = Lpad; a.O = E->ctx; a.ldo = D; a.B = B; a.H = H; a.L = N; a.hd = HD;
-    a.dtype = dt; a.scale = 0.125f; a.causal = 0; a.period = 1;
+    a.dtype = dtl; a.scale = 0.125f; a.causal = 0; a.period = 1;
+    a.q_lo_off = lo_md; a.kv_lo_off = lo_kv; a.o_lo_off = lo_md;
     return fdm_op_attention(&a, stream);
   };
   if (E->stable_ln) {       // pre-LN layers, final LayerNorm (HubertEncoderStableLayerNorm)
     for (const Layer& ly : E->layers) {
-      FCK(layernorm(h, ly.ln1g, ly.ln1b, M, D, FDM_ACT_NONE, nullptr, E->xt, dt, stream));
+      FCK(lnorm(h, ly.ln1g, ly.ln1b, nullptr, E->xt));
       FCK(qkv(E->xt, ly));
       FCK(attn());
-      fdm_gemm_args a = gemm_args(dt, E->ctx, ly.wo.p, M, D, D);
+      fdm_gemm_args a = lgemm(E->ctx, lo_md, ly.wo, D, D);
       a.bias = ly.bo; a.resid = h; a.out_f32 = hb;
       FCK(fdm_op_gemm(&a, stream));
-      FCK(layernorm(hb, ly.ln2g, ly.ln2b, M, D, FDM_ACT_NONE, nullptr, E->xt, dt, stream));
-      a = gemm_args(dt, E->xt, ly.w1.p, M, FFN, D);
-      a.bias = ly.b1; a.act = FDM_ACT_GELU_ERF; a.out_t = E->u;
+      FCK(lnorm(hb, ly.ln2g, ly.ln2b, nullptr, E->xt));
+      a = lgemm(E->xt, lo_md, ly.w1, FFN, D);
+      a.bias = ly.b1; a.act = FDM_ACT_GELU_ERF; a.out_t = E->u; a.out_t_lo_off = lo_mf;
       FCK(fdm_op_gemm(&a, stream));
-      a = gemm_args(dt, E->u, ly.w2.p, M, D, FFN);
+      a = lgemm(E->u, lo_mf, ly.w2, D, FFN);
       a.bias = ly.b2; a.resid = hb; a.out_f32 = h;
       FCK(fdm_op_gemm(&a, stream));
     }
-    FCK(layernorm(h, E->fin_g, E->fin_b, M, D, FDM_ACT_NONE, out, nullptr, dt, stream));
+    FCK(lnorm(h, E->fin_g, E->fin_b, out, nullptr));
   } else {                  // LayerNorm before the stack, post-LN layers (Wav2Vec2Encoder / Wav2Vec2EncoderLayer)
-    const bool both = dt == FDM_BF16;
+    const bool both = dtl != FDM_F32;
     void* htt = both ? E->xt : nullptr;
-    FCK(layernorm(h, E->fin_g, E->fin_b, M, D, FDM_ACT_NONE, hb, htt, dt, stream));
+    FCK(lnorm(h, E->fin_g, E->fin_b, hb, htt));
     for (const Layer& ly : E->layers) {
       const void* a_in = both ? (const void*)E->xt : (const void*)hb;
       FCK(qkv(a_in, ly));
       FCK(attn());
-      fdm_gemm_args a = gemm_args(dt, E->ctx, ly.wo.p, M, D, D);
+      fdm_gemm_args a = lgemm(E->ctx, lo_md, ly.wo, D, D);
       a.bias = ly.bo; a.resid = hb; a.out_f32 = E->x1;
       FCK(fdm_op_gemm(&a, stream));
-      FCK(layernorm(E->x1, ly.ln1g, ly.ln1b, M, D, FDM_ACT_NONE, hb, htt, dt, stream));
-      a = gemm_args(dt, a_in, ly.w1.p, M, FFN, D);
-      a.bias = ly.b1; a.act = FDM_ACT_GELU_ERF; a.out_t = E->u;
+      FCK(lnorm(E->x1, ly.ln1g, ly.ln1b, hb, htt));
+      a = lgemm(a_in, lo_md, ly.w1, FFN, D);
+      a.bias = ly.b1; a.act = FDM_ACT_GELU_ERF; a.out_t = E->u; a.out_t_lo_off = lo_mf;
       FCK(fdm_op_gemm(&a, stream));
-      a = gemm_args(dt, E->u, ly.w2.p, M, D, FFN);
+      a = lgemm(E->u, lo_mf, ly.w2, D, FFN);
       a.bias = ly.b2; a.resid = hb; a.out_f32 = E->x1;
       FCK(fdm_op_gemm(&a, stream));
-      FCK(layernorm(E->x1, ly.ln2g, ly.ln2b, M, D, FDM_ACT_NONE, hb, htt, dt, stream));
+      FCK(lnorm(E->x1, ly.ln2g, ly.ln2b, hb, htt));
     }
     HIPCK(hipMemcpyAsync(out, hb, (size_t)M * D * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   }

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, presets, schedule, synth
-from ._lib import BF16, DTYPE_NAMES, F32, FdmError
+from ._lib import BF16, DTYPE_NAMES, F16X3, F32, FdmError
 from .denoiser import DenoiserPlan
 from .hubert import HUBERT_LARGE, WAV2VEC2_BASE, HubertPlan, num_frames
 from .vq import VQPlan
@@ -41,8 +41,14 @@ def compute_dtype(name=None):
 
 
 def _side_dtype(dt):
-    """The once-per-clip stages (audio encoder, VQ quant / decode) run in fp32 when the step program uses split operands."""
+    """VQ quant / decode (once per clip) run in fp32 when the step program uses split operands."""
     return dt if dt in (F32, BF16) else F32
+
+
+def _audio_dtype(dt):
+    """The audio encoders follow the step program's mode where they have it: fp32, bf16, or f16x3 (split-fp16 transformer layers
+    behind an fp32 conv front: inside the 1e-4 contract at 0.57x the fp32 encoder's time); bf16x3 falls back to fp32."""
+    return dt if dt in (F32, BF16, F16X3) else F32
 
 
 class ParamTree(nn.Module):
@@ -160,7 +166,7 @@ class HubertModel(ParamTree):
 
     def _get_plan(self, device):
         if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
-            self._plan = HubertPlan(self.state_dict(), self.n_layers, _side_dtype(self._dtype), device)
+            self._plan = HubertPlan(self.state_dict(), self.n_layers, _audio_dtype(self._dtype), device)
             self._plan_stale = False
         return self._plan
 
@@ -194,7 +200,7 @@ class Wav2Vec2Model(HubertModel):
 
     def _get_plan(self, device):
         if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
-            self._plan = HubertPlan(self.state_dict(), self.n_layers, _side_dtype(self._dtype), device, cfg=WAV2VEC2_BASE)
+            self._plan = HubertPlan(self.state_dict(), self.n_layers, _audio_dtype(self._dtype), device, cfg=WAV2VEC2_BASE)
             self._plan_stale = False
         return self._plan
 

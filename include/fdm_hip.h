@@ -414,7 +414,9 @@ int fdm_plan_set(fdm_plan* p, const char* key, long long value);    /* "tile.<ca
  * forward: wav [B, n] processor-normalised fp32 -> out [B, N, D] fp32, *n_frames = N = fdm_hubert_frames(n) (the conv
  * stack's length, even-cropped, :95-96).  frame_num > 0 keeps at most 2 * frame_num frames (:97-98); interp_in_fps /
  * interp_out_fps > 0 resample the conv features (linear_interpolation, :62-69) to frame_num or int(T / in * out) frames
- * instead of the even crop.  The caller sizes `out` for fdm_hubert_frames(n) rows per clip (or the interpolated count). */
+ * instead of the even crop.  The caller sizes `out` for fdm_hubert_frames(n) rows per clip (or the interpolated count).
+ * dtype: FDM_F32, FDM_BF16, or FDM_F16X3 = the transformer layers (84 % of the FLOPs) on split-fp16 operands behind an fp32
+ * conv front / projection / positional conv: inside the 1e-4 contract at 0.57x the fp32 encoder's time. */
 typedef struct fdm_audio_encoder fdm_audio_encoder;
 int fdm_hubert_create(int kind, int n_layers, int dtype, fdm_audio_encoder** out);
 int fdm_hubert_set_weights(fdm_audio_encoder* e, const char* name, const float* ptr, long long n, void* stream);

@@ -139,7 +139,8 @@ def test_plan_layer_argument_validation_without_device():
     assert l.fdm_plan_destroy(None) == 0
     h = C.c_void_p()
     assert l.fdm_hubert_create(2, 0, 0, C.byref(h)) == -1 and b"kind" in l.fdm_last_error()
-    assert l.fdm_hubert_create(0, 0, _lib.F16X3, C.byref(h)) == -1                       # the once-per-clip stages: fp32 / bf16
+    assert l.fdm_hubert_create(0, 0, _lib.BF16X3, C.byref(h)) == -1                      # audio encoders: fp32 / bf16 / f16x3 (split-fp16 layers)
+    assert l.fdm_hubert_create(0, 0, _lib.F16X3, C.byref(h)) == 0 and l.fdm_hubert_destroy(h) == 0
     assert l.fdm_hubert_create(1, 0, 0, C.byref(h)) == 0                                 # creation itself needs no device
     assert l.fdm_hubert_set_weights(h, b"encoder.layer_norm.weight", None, 768, None) == -1
     assert l.fdm_hubert_destroy(h) == 0

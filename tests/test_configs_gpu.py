@@ -86,19 +86,19 @@ def test_cfg4_biwi_full_ddim_chain(dtype):
 
 # cfg5 in every arithmetic mode bench.py offers for it.  (denoiser mode, once-per-clip stages' mode, bar on the first 5 steps of
 # the chain vs the oracle fed the SAME HIP audio features).  The bf16 bar is 2x the measured distance (1.5e-4 over these 5 steps at t = 999..995, whose update coefficients are tiny; round 3);
-# the parity modes state the contract's 1e-4.  f16x3 runs HuBERT / quant / decode in fp32 (bench.py does the same).
-CFG5_MODES = {"f32": (F32, F32, TOL), "bf16": (BF16, BF16, 3e-4), "f16x3": (F16X3, F32, TOL)}
+# the parity modes state the contract's 1e-4.  f16x3 runs HuBERT with split-fp16 layers and quant / decode in fp32 (bench.py does the same).
+CFG5_MODES = {"f32": (F32, F32, F32, TOL), "bf16": (BF16, BF16, BF16, 3e-4), "f16x3": (F16X3, F16X3, F32, TOL)}
 
 
 @pytest.mark.parametrize("mode", ["f32", "bf16", "f16x3"])
 def test_cfg5_vocaset_end_to_end_composed(mode):
     from fdm_amd.hubert import HubertPlan
     from fdm_amd.vq import VQPlan
-    dt, side_dt, bar = CFG5_MODES[mode]
+    dt, hub_dt, side_dt, bar = CFG5_MODES[mode]
     preset, B, T = "vocaset", 4, 1000
     w = W.make_fdm_weights(preset)
     wav = (torch.randn(B, 160000, generator=torch.Generator().manual_seed(100)) * 0.1).to(DEV)
-    hub_plan = HubertPlan(W.make_hubert_weights(24), 24, side_dt, DEV)
+    hub_plan = HubertPlan(W.make_hubert_weights(24), 24, hub_dt, DEV)
     vq_plan = VQPlan(preset, W.make_vq_weights(preset), side_dt, DEV)
     hub = hub_plan.forward(wav)
     assert hub.shape == (B, 498, 1024) and torch.isfinite(hub).all()

@@ -53,6 +53,36 @@ def test_hubert_bf16_stated_tolerance(golden):
     assert mad(out[0], g["out_L24_2s"]) < 0.054  # 24 bf16 layers on O(4) activations: 2x the measured 2.69e-2 (tools/measure_bf16_bars.py, round 3)
 
 
+def test_audio_encoders_in_the_contract_mode_vs_golden(golden):
+    """FDM_F16X3 audio encoders (split-fp16 transformer layers behind an fp32 conv front, csrc/encoders.hip): inside the 1e-4
+    contract against the same reference goldens as the fp32 encoders -- HuBERT-large 2 / 24 layers, 2 s and 10 s; wav2vec2-base
+    (post-LN, d = 768) -- and a batch equals its clips run one at a time."""
+    from fdm_amd._lib import F16X3
+    from fdm_amd.hubert import WAV2VEC2_BASE
+    g = golden("hubert")
+    p2 = HubertPlan(W.make_hubert_weights(2), 2, F16X3, DEV)
+    d2 = mad(p2.forward(wav_for(2, 32000))[0], g["out_L2_2s"])
+    p24 = HubertPlan(W.make_hubert_weights(24), 24, F16X3, DEV)
+    d24 = mad(p24.forward(wav_for(2, 32000))[0], g["out_L24_2s"])
+    o10 = p24.forward(wav_for(10, 160000))
+    d10 = mad(o10[0, ::8], g["out_L24_10s_rows8"])
+    print(f"hubert f16x3 vs reference: 2 layers {d2:.2e}, 24 layers 2 s {d24:.2e}, 10 s {d10:.2e}")
+    assert o10.shape == (1, 498, 1024) and max(d2, d24, d10) < 1e-4
+    two = torch.stack([wav_for(2, 32000), wav_for(3, 32000)])
+    ob = p24.forward(two)
+    assert torch.equal(ob[0], p24.forward(two[0])[0]) and torch.equal(ob[1], p24.forward(two[1])[0])
+    gw = golden("wav2vec")
+
+    def wv(secs, n):
+        gg = torch.Generator().manual_seed(20 + secs)
+        return HO.processor_normalize(torch.randn(n, generator=gg) * 0.1)
+    p12 = HubertPlan(W.make_wav2vec_weights(12), 12, F16X3, DEV, cfg=WAV2VEC2_BASE)
+    dw = mad(p12.forward(wv(2, 32000))[0], gw["out_L12_2s"])
+    dw10 = mad(p12.forward(wv(10, 160000))[0, ::8], gw["out_L12_10s_rows8"])
+    print(f"wav2vec2 f16x3 vs reference: 2 s {dw:.2e}, 10 s {dw10:.2e}")
+    assert max(dw, dw10) < 1e-4
+
+
 def vq_case(preset, L, e):
     p = W.PRESETS[preset]
     w = W.make_vq_weights(preset)

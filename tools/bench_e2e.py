@@ -3,12 +3,12 @@ HuBERT once -> 1000-step DDPM -> quant -> decode)."""
 import sys, time, torch
 sys.path.insert(0, 'face-diffusion-model_amd')
 from fdm_amd import synth
-from fdm_amd._lib import BF16, F32
+from fdm_amd._lib import BF16, F16X3, F32
 from fdm_amd.denoiser import DenoiserPlan
 from fdm_amd.hubert import HubertPlan, num_frames
 from fdm_amd.vq import VQPlan
 DEV = 'cuda:0'
-dt = BF16 if (len(sys.argv) < 2 or sys.argv[1] == 'bf16') else F32
+dt = {'bf16': BF16, 'f16x3': F16X3}.get(sys.argv[1] if len(sys.argv) > 1 else 'bf16', F32)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 secs = float(sys.argv[3]) if len(sys.argv) > 3 else 10.0
 T = int(sys.argv[4]) if len(sys.argv) > 4 else 1000
@@ -21,7 +21,7 @@ def timed(name, fn, reps=1):
     return out, t
 hub_plan = HubertPlan(synth.make_hubert_weights(24), 24, dt, DEV)
 den = DenoiserPlan('vocaset', synth.make_fdm_weights('vocaset'), dt, DEV)
-vq = VQPlan('vocaset', synth.make_vq_weights('vocaset'), dt, DEV)
+vq = VQPlan('vocaset', synth.make_vq_weights('vocaset'), F32 if dt == F16X3 else dt, DEV)
 n = int(secs * 16000)
 g = torch.Generator().manual_seed(0)
 wav = (torch.randn(B, n, generator=g) * 0.1).to(DEV)
@@ -41,5 +41,5 @@ vq.decode(vq.quant(lat)[0])
 out, t_d = timed('vq decode', lambda: vq.decode(zq))
 tot = t_h + t_p + t_s + t_q + t_d
 fl_h = 2 * B * L * 24 * (4 * 1024 * 1024 + 2 * 1024 * 4096) + 24 * B * 4 * L * L * 1024
-print(f"B={B} L={L} dtype={'bf16' if dt == BF16 else 'f32'}: end-to-end {tot*1e3:.1f} ms -> {B*L/tot:.1f} frames/s "
+print(f"B={B} L={L} dtype={ {BF16: 'bf16', F16X3: 'f16x3'}.get(dt, 'f32') }: end-to-end {tot*1e3:.1f} ms -> {B*L/tot:.1f} frames/s "
       f"(sampling share {100*t_s/tot:.1f}%); hubert encoder layers ~{fl_h/t_h/1e12:.0f} TFLOP/s")
