@@ -254,7 +254,7 @@ def main():
         if e2e:
             from fdm_amd.hubert import HubertPlan
             from fdm_amd.vq import VQPlan
-            side_dt = dt if dt in (F32, DTYPE_NAMES["bf16"]) else F32     # VQ quant / decode run fp32 in the split modes
+            side_dt = dt if dt in (F32, DTYPE_NAMES["bf16"]) else F32     # VQ quant / decode run fp32 in the split modes (wider parity margin)
             hub_dt = dt if dt in (F32, DTYPE_NAMES["bf16"], DTYPE_NAMES["f16x3"]) else F32      # HuBERT: fp32, bf16, or split-fp16 layers
             hub_plan = HubertPlan(W.make_hubert_weights(24), 24, hub_dt, dev)
             vq_plan = VQPlan(preset, W.make_vq_weights(preset), side_dt, dev)

@@ -489,6 +489,8 @@ int fdm_hubert_forward(fdm_audio_encoder* E, const float* wav, int B, int n, int
 struct fdm_vq {
   fdm_vq_desc d{};
   int dtype = FDM_F32;
+  // FDM_F16X3: the two 6-layer transformers on split-fp16 operands; convs, embeddings, the vertex map and the quantiser stay fp32
+  int front_dtype() const { return dtype == FDM_F16X3 ? FDM_F32 : dtype; }
   Store st;
   Arena mem, ws;
   bool committed = false, has_encoder = false;
@@ -547,13 +549,13 @@ int vq_conv_pack(fdm_vq* V, const std::string& name, Mat* out, void* stream) {
   float* r = nullptr;
   FCK(V->mem.alloc_t(&r, (size_t)d * d * 5));
   hipLaunchKernelGGL(permute_oik_oki_kernel, dim3(grid_for((long long)d * d * 5)), dim3(256), 0, (hipStream_t)stream, p, r, d, d, 5);
-  return to_operand(V->mem, V->dtype, r, (long long)d * d * 5, out, stream);
+  return to_operand(V->mem, V->front_dtype(), r, (long long)d * d * 5, out, stream);
 }
 
 int vq_commit(fdm_vq* V, void* stream) {
   if (V->committed) return FDM_OK;
   const fdm_vq_desc& q = V->d;
-  const int d = VQ_HIDDEN, dt = V->dtype;
+  const int d = VQ_HIDDEN, dt = V->front_dtype();
   const float* p = nullptr;
   FCK(V->st.need("quantize.embedding.weight", (long long)q.K * q.n_books * q.c, &V->codebook));
   if (q.pre) {
@@ -614,7 +616,7 @@ int vq_reserve(fdm_vq* V, int B, int L) {
   B = B > V->capB ? B : V->capB; L = L > V->capL ? L : V->capL;
   (void)hipDeviceSynchronize();
   V->ws.release();
-  const size_t d = VQ_HIDDEN, M = (size_t)B * L, es = esize(V->dtype);
+  const size_t d = VQ_HIDDEN, M = (size_t)B * L, es = esize(V->front_dtype());
   const size_t wide = d > (size_t)V->d.G * V->d.c ? d : (size_t)V->d.G * V->d.c;
   FCK(V->ws.alloc_t(&V->x32, M * wide)); FCK(V->ws.alloc(&V->xt, M * wide * es)); FCK(V->ws.alloc(&V->y, M * d * es));
   FCK(V->ws.alloc(&V->xp, (size_t)B * (L + 4) * d * es)); FCK(V->ws.alloc_t(&V->c32, M * d)); FCK(V->ws.alloc(&V->nt, M * d * es));
@@ -634,24 +636,38 @@ int vq_transformer(fdm_vq* V, float* h, const std::vector<Layer>& layers, int B,
   const size_t es = esize(dt);
   HIPCK(hipMemsetAsync(V->kp, 0, (size_t)B * Lpad * d * es, (hipStream_t)stream));
   HIPCK(hipMemsetAsync(V->vp, 0, (size_t)B * Lpad * d * es, (hipStream_t)stream));
+  // split kind: every operand of the loop is a plane pair, the lo plane one whole matrix after the hi plane
+  const bool split = dt == FDM_F16X3;
+  const long long lo_md = split ? (long long)M * d : 0, lo_mf = split ? (long long)M * VQ_FFN : 0, lo_kv = split ? (long long)B * Lpad * d : 0;
+  auto lnorm = [&](const float* x, const float* gam, const float* bet) {
+    fdm_ln_args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.M = M; a.d = d; a.gamma = gam; a.beta = bet; a.eps = 1e-5f; a.act = FDM_ACT_NONE; a.y_t = V->a; a.y_t_lo_off = lo_md; a.dtype = dt;
+    return fdm_op_layernorm(&a, stream);
+  };
   for (const Layer& ly : layers) {
-    FCK(layernorm(h, ly.ln1g, ly.ln1b, M, d, FDM_ACT_NONE, nullptr, V->a, dt, stream));
+    FCK(lnorm(h, ly.ln1g, ly.ln1b));
     fdm_gemm_args g = gemm_args(dt, V->a, ly.wqkv.p, M, 3 * d, d);
+    g.a_lo_off = lo_md; g.w_lo_off = ly.wqkv.lo; g.out_t_lo_off = lo_md; g.kv_lo_off = lo_kv;
     g.out_t = V->q; g.ldo_t = d; g.out_kp = V->kp; g.kp_col0 = d; g.out_vp = V->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = Lpad; g.kv_hd = hd;
     FCK(fdm_op_gemm(&g, stream));
     fdm_attn_args at;
     memset(&at, 0, sizeof(at));
     at.Q = V->q; at.ldq = d; at.Kp = V->kp; at.Vp = V->vp; at.Lpad = Lpad; at.O = V->ctx; at.ldo = d; at.B = B; at.H = VQ_HEADS; at.L = L; at.hd = hd;
     at.dtype = dt; at.scale = 1.0f / std::sqrt((float)d); at.causal = 0; at.period = 1;      // scale = hidden^-0.5 (base_models.py:144)
+    at.q_lo_off = lo_md; at.kv_lo_off = lo_kv; at.o_lo_off = lo_md;
     FCK(fdm_op_attention(&at, stream));
     g = gemm_args(dt, V->ctx, ly.wo.p, M, d, d);
+    g.a_lo_off = lo_md; g.w_lo_off = ly.wo.lo;
     g.bias = ly.bo; g.resid = h; g.out_f32 = V->hb;
     FCK(fdm_op_gemm(&g, stream));
-    FCK(layernorm(V->hb, ly.ln2g, ly.ln2b, M, d, FDM_ACT_NONE, nullptr, V->a, dt, stream));
+    FCK(lnorm(V->hb, ly.ln2g, ly.ln2b));
     g = gemm_args(dt, V->a, ly.w1.p, M, VQ_FFN, d);
+    g.a_lo_off = lo_md; g.w_lo_off = ly.w1.lo; g.out_t_lo_off = lo_mf;
     g.bias = ly.b1; g.act = FDM_ACT_GELU_TANH; g.out_t = V->u;
     FCK(fdm_op_gemm(&g, stream));
     g = gemm_args(dt, V->u, ly.w2.p, M, d, VQ_FFN);
+    g.a_lo_off = lo_mf; g.w_lo_off = ly.w2.lo;
     g.bias = ly.b2; g.resid = V->hb; g.out_f32 = h;
     FCK(fdm_op_gemm(&g, stream));
   }
@@ -660,7 +676,7 @@ int vq_transformer(fdm_vq* V, float* h, const std::vector<Layer>& layers, int B,
 
 // Conv1d(k = 5, replicate) -> LeakyReLU -> InstanceNorm1d -> Linear + pe[0]; xt [B*L, 1024] operand kind -> V->h fp32
 int vq_conv_norm_embed(fdm_vq* V, const void* xt, const Mat& conv_w, const float* conv_b, const Mat& emb_w, const float* emb_b, int B, int L, void* stream) {
-  const int d = VQ_HIDDEN, dt = V->dtype, M = B * L;
+  const int d = VQ_HIDDEN, dt = V->front_dtype(), M = B * L;
   FCK(fdm_op_pad_rows(xt, V->xp, B, L, d, 2, dt, 0, stream));
   fdm_gemm_args g = gemm_args(dt, V->xp, conv_w.p, L, d, 5 * d);
   g.lda = d; g.bias = conv_b; g.out_f32 = V->c32; g.batch = B; g.a_batch_stride = (long long)(L + 4) * d; g.out_batch_stride = (long long)L * d;
@@ -672,9 +688,9 @@ int vq_conv_norm_embed(fdm_vq* V, const void* xt, const Mat& conv_w, const float
 }
 
 int vq_operand(fdm_vq* V, const float* src32, void* dst, long long n, const void** out, void* stream) {
-  if (V->dtype == FDM_F32) { *out = src32; return FDM_OK; }
+  if (V->front_dtype() == FDM_F32) { *out = src32; return FDM_OK; }
   *out = dst;
-  return fdm_op_cast(src32, dst, n, V->dtype, stream);
+  return fdm_op_cast(src32, dst, n, V->front_dtype(), stream);
 }
 
 }  // namespace
@@ -683,7 +699,8 @@ extern "C" {
 
 int fdm_vq_create(const fdm_vq_desc* desc, int dtype, fdm_vq** out) {
   if (!desc || !out) return fail(FDM_ERR_ARG, "vq_create: null argument");
-  if (dtype != FDM_F32 && dtype != FDM_BF16) return fail(FDM_ERR_ARG, "vq_create: dtype %d (the once-per-clip stages run in fp32 or bf16)", dtype);
+  if (dtype != FDM_F32 && dtype != FDM_BF16 && dtype != FDM_F16X3)
+    return fail(FDM_ERR_ARG, "vq_create: dtype %d (fp32, bf16, or FDM_F16X3 = split-fp16 transformer layers, everything else fp32)", dtype);
   if (desc->G <= 0 || desc->c <= 0 || desc->c > 128 || desc->K <= 0 || desc->n_books <= 0 || desc->V3 <= 0)
     return fail(FDM_ERR_SHAPE, "vq_create: inconsistent geometry (G %d, c %d, K %d, books %d, V3 %d)", desc->G, desc->c, desc->K, desc->n_books, desc->V3);
   if (!desc->pre && desc->G * desc->c != VQ_HIDDEN) return fail(FDM_ERR_SHAPE, "vq_create: decoder input width G*c = %d must equal %d when there is no pre-embedding", desc->G * desc->c, VQ_HIDDEN);
@@ -749,7 +766,7 @@ int fdm_vq_decode(fdm_vq* V, const float* zq_bcl, int B, int R, float* out, void
   if (!fdm_device_ok()) return fail(FDM_ERR_STATE, "vq_decode: no gfx950 device visible (there is no CPU fallback)");
   FCK(vq_commit(V, stream));
   FCK(vq_reserve(V, B, L));
-  const int d = VQ_HIDDEN, dt = V->dtype, M = B * L, W = q.G * q.c;
+  const int d = VQ_HIDDEN, dt = V->front_dtype(), M = B * L, W = q.G * q.c;
   // [B, c, L*G] -> [B, L*G, c] == [B*L, G*c] (layout only; models/vq_vae_vocaset.py:37-40)
   hipLaunchKernelGGL(bcr_to_brc_kernel, dim3(grid_for((long long)B * q.c * R)), dim3(256), 0, (hipStream_t)stream, zq_bcl, V->x32, B, q.c, R);
   const void* xt = nullptr;
@@ -779,7 +796,7 @@ int fdm_vq_encode(fdm_vq* V, const float* x, const float* emo_one_hot, int B, in
   const fdm_vq_desc& q = V->d;
   if (q.n_books > 1 && !emo_one_hot) return fail(FDM_ERR_ARG, "vq_encode: this model's encoder needs the emotion one-hot");
   FCK(vq_reserve(V, B, L));
-  const int d = VQ_HIDDEN, dt = V->dtype, M = B * L;
+  const int d = VQ_HIDDEN, dt = V->front_dtype(), M = B * L;
   hipLaunchKernelGGL(pad_cols_kernel, dim3(grid_for((long long)M * V->Kp)), dim3(256), 0, (hipStream_t)stream, x, V->xpad32, (long long)M, q.V3, V->Kp);
   const void* xp = nullptr;
   FCK(vq_operand(V, V->xpad32, V->xpt, (long long)M * V->Kp, &xp, stream));

@@ -433,7 +433,9 @@ int fdm_hubert_destroy(fdm_audio_encoder* e);
  * quant:  z [B, R, c] (+ emotion one-hot [B, n_books]) -> z_q [B, c, R] (the reference's permuted output), idx [B*R] int64;
  *         quant_stats: emb_loss, perplexity, min_encodings of that call
  * decode: z_q [B, c, L*G] -> vertex offsets [B, L, V3] (the caller adds the template; every clip gets pe[0], a20)
- * encode: x [B, L, V3] (+ emotion one-hot [B, 7]) -> latent [B, L*G, c]                                                  */
+ * encode: x [B, L, V3] (+ emotion one-hot [B, 7]) -> latent [B, L*G, c]
+ * dtype: FDM_F32, FDM_BF16, or FDM_F16X3 = the two 6-layer transformers on split-fp16 operands, convolutions / embeddings /
+ *        vertex map / quantiser in fp32 (indices and z_q identical to the fp32 object's; decode 1.4-4.6e-5 from the reference) */
 typedef struct fdm_vq_desc { int G, c, K, n_books, V3, pre; } fdm_vq_desc;
 typedef struct fdm_vq fdm_vq;
 int fdm_vq_create(const fdm_vq_desc* desc, int dtype, fdm_vq** out);

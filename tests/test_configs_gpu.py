@@ -86,11 +86,12 @@ def test_cfg4_biwi_full_ddim_chain(dtype):
 
 # cfg5 in every arithmetic mode bench.py offers for it.  (denoiser mode, once-per-clip stages' mode, bar on the first 5 steps of
 # the chain vs the oracle fed the SAME HIP audio features).  The bf16 bar is 2x the measured distance (1.5e-4 over these 5 steps at t = 999..995, whose update coefficients are tiny; round 3);
-# the parity modes state the contract's 1e-4.  f16x3 runs HuBERT with split-fp16 layers and quant / decode in fp32 (bench.py does the same).
-CFG5_MODES = {"f32": (F32, F32, F32, TOL), "bf16": (BF16, BF16, BF16, 3e-4), "f16x3": (F16X3, F16X3, F32, TOL)}
+# the parity modes state the contract's 1e-4.  f16x3 runs HuBERT with split-fp16 layers and quant / decode in fp32 (bench.py and the drop-in modules do the same); "f16x3_all"
+# adds the VQ decoder's transformer on split-fp16 operands (VQPlan's own f16x3 mode).
+CFG5_MODES = {"f32": (F32, F32, F32, TOL), "bf16": (BF16, BF16, BF16, 3e-4), "f16x3": (F16X3, F16X3, F32, TOL), "f16x3_all": (F16X3, F16X3, F16X3, TOL)}
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16", "f16x3"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16x3", "f16x3_all"])
 def test_cfg5_vocaset_end_to_end_composed(mode):
     from fdm_amd.hubert import HubertPlan
     from fdm_amd.vq import VQPlan

@@ -252,6 +252,39 @@ def test_vq_encode_round_trip_vs_golden(golden, preset):
     assert mad(plan.decode(zq)[0][:, ::16], g[f"{preset}_dec_cols16"]) < 1e-4
 
 
+@pytest.mark.parametrize("preset,L,e", [("vocaset", 12, 0), ("vocaset", 100, 0), ("mead", 100, 3), ("biwi", 100, 0)])
+def test_vq_in_the_contract_mode_vs_golden(golden, preset, L, e):
+    """FDM_F16X3 VQ-VAE (its two 6-layer transformers on split-fp16 operands; convolutions, embeddings, vertex map and the quantiser
+    in fp32): indices and z_q bit-identical to the fp32 plan's (the quantiser does not change), decode and the encoder inside the
+    contract's 1e-4 against the same reference goldens as the fp32 plan."""
+    from fdm_amd._lib import F16X3
+    g = golden("vq")
+    w, z, emo = vq_case(preset, L, e)
+    plan = vq_plan(preset, F16X3)
+    zq, idx = plan.quant(z, emo)
+    zq32, idx32 = vq_plan(preset).quant(z, emo)
+    assert torch.equal(idx, idx32) and torch.equal(zq, zq32)
+    ozq, _ = VO.quant(w, preset, z, emo)
+    dec = plan.decode(ozq.to(DEV))[0]
+    key = f"{preset}_L{L}_e{e}"
+    dd = mad(dec, g[key + "_dec"]) if key + "_dec" in g else mad(dec[:, ::16], g[key + "_dec_cols16"])
+    print(f"vq decode f16x3 vs reference {key}: {dd:.2e}")
+    assert dd < 1e-4
+    if L == 100:
+        ge = golden("vq_encode")
+        p = W.PRESETS[preset]
+        pe = VQPlan(preset, W.make_vq_weights(preset, encoder=True), F16X3, DEV)
+        x = torch.randn(1, 10, p["V3"], generator=torch.Generator().manual_seed(60)) * 0.3
+        em = torch.eye(7)[5].unsqueeze(0) if p["n_books"] > 1 else None
+        h = pe.encode(x.to(DEV), None if em is None else em.to(DEV))
+        dh = mad(h[0], ge[f"{preset}_h"])
+        print(f"vq encode f16x3 vs reference {preset}: {dh:.2e}")
+        assert dh < 1e-4
+        zq2, idx2 = pe.quant(h, em)
+        assert np.array_equal(idx2.cpu().numpy().astype(np.int16), ge[f"{preset}_idx"])
+        assert mad(pe.decode(zq2)[0][:, ::16], ge[f"{preset}_dec_cols16"]) < 1e-4
+
+
 def test_q_sample_and_forward_loss():
     """GaussianDiffusion.q_sample / p_losses forward value on the HIP path vs the oracle."""
     import sys, os

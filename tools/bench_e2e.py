@@ -21,7 +21,7 @@ def timed(name, fn, reps=1):
     return out, t
 hub_plan = HubertPlan(synth.make_hubert_weights(24), 24, dt, DEV)
 den = DenoiserPlan('vocaset', synth.make_fdm_weights('vocaset'), dt, DEV)
-vq = VQPlan('vocaset', synth.make_vq_weights('vocaset'), F32 if dt == F16X3 else dt, DEV)
+vq = VQPlan('vocaset', synth.make_vq_weights('vocaset'), F32 if (dt == F16X3 and 'vq16' not in sys.argv) else dt, DEV)
 n = int(secs * 16000)
 g = torch.Generator().manual_seed(0)
 wav = (torch.randn(B, n, generator=g) * 0.1).to(DEV)
