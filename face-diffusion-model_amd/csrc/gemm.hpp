@@ -963,6 +963,11 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
     // below that the 64x64 tile's extra blocks beat its higher L2->LDS traffic.
     static const long long thr128 = [] { const char* e = getenv("FDM_GEMM_T128"); return e ? atoll(e) : 512LL; }();
     static const long long thr128x64 = [] { const char* e = getenv("FDM_GEMM_T128X64"); return e ? atoll(e) : 700LL; }();
+    const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128) * batch;
+    // thousands of rows: the ping-pong loop on the 256x128 tile (the tuner's pick for the N <= 2048 sites from 6400 rows and
+    // for FFN1 from 3200; `profiles/r3_rows_sweep`, `r3_tile_sweep`; bf16 only, whole column tiles)
+    const bool pp_ok = gemm_rules_on() && elem_bytes == 2 && a.N % 128 == 0 && a.K >= 1024;
+    if (pp_ok && a.M >= 6000 && a.N <= 2048 && t256 >= 150) return FDM_TILE_256x128_PP;
     if (t128 >= thr128) return FDM_TILE_128x128;
     if (gemm_one_round_80(a)) return FDM_TILE_80x128;
     // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two
@@ -971,8 +976,8 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
       // 1100..4000 rows (batched clips, long clips, CFG): what the plan-time tuner picks there (profiles/r3_tile_sweep/), as rules.
       // A grid that fills the chip in exactly ONE round wins; else 128x64 -- on the 4-stage ring while its grid is one round, on the
       // 3-stage ring (72 KB: two workgroups per CU, all of <= 512 tiles resident) beyond.
-      const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128) * batch;
       if (gemm_one_round(t128)) return FDM_TILE_128x128;
+      if (pp_ok && gemm_one_round(t256) && a.M >= 3000) return FDM_TILE_256x128_PP;
       if (gemm_one_round(t256)) return FDM_TILE_256x128;
       if (t128x64 > 128) return t128x64 <= 256 ? FDM_TILE_128x64 : FDM_TILE_128x64_S3;
     }
@@ -995,11 +1000,19 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
   return FDM_TILE_64x64;
 }
 
+// the scheduler-fused latent decoder has two forms (64x64, ping-pong 256x128): the same rule as its unfused shape
+static bool gemm_sched_fuse_heuristic_pp(const fdm_gemm_args& a, int elem_bytes) {
+  fdm_gemm_args b = a;
+  b.sched_fuse = 0;
+  return gemm_heuristic_tile(b, elem_bytes, false) == FDM_TILE_256x128_PP;
+}
+
 template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   if (a.sched_fuse) {     // (validated: interior tiles only -> the lean epilogue)
     // thousands of rows: the scheduler-fused latent decoder on the ping-pong tile when the plan's tuner picked it
-    if (a.tile == FDM_TILE_256x128_PP && !a.ln_stat_in && a.N % 128 == 0)
+    const bool pp = a.tile == FDM_TILE_256x128_PP || (a.tile == 0 && gemm_tile_override() == 0 && gemm_sched_fuse_heuristic_pp(a, (int)sizeof(typename Opnd<T>::E)));
+    if (pp && !a.ln_stat_in && a.N % 128 == 0)
       return gemm_pp_launch_h<T, 256, 128, 4, 2, 3, false, true, GEMM_LEAN>(a, s);
     return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
                         : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);

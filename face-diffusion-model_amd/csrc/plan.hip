@@ -1001,7 +1001,7 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
     const int heur = launched(fdm_gemm_heuristic_tile(&kv.second[0]));
     for (int tile : cands) {
       if (launched(tile) == heur) continue;
-      if (kv.second[0].sched_fuse && tile != FDM_TILE_256x128_PP) continue;      // the scheduler-fused decoder has two forms: 64x64 and the ping-pong tile
+      if (kv.second[0].sched_fuse && tile != FDM_TILE_256x128_PP && tile != FDM_TILE_64x64) continue;      // the scheduler-fused decoder has two forms: 64x64 and the ping-pong tile
       if (modelled_us(kv.second[0], tile) > 1.35 * best_model) continue;
       float t = 0.f;
       FCK(timed(inst, tile, &t));

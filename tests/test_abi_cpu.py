@@ -191,6 +191,8 @@ def test_tile_heuristic_is_a_pure_function_of_the_shape():
     assert tile(B, 1200, 512, 512) == _lib.TILE_64x64                   # MEAD's short-K sites stay on the resident 64x64 grid
     assert tile(F, 1992, 2048, 1024) == _lib.TILE_64x64 and tile(F, 1200, 1024, 1024) == _lib.TILE_64x64
     assert tile(B, 6400, 3072, 1024) == _lib.TILE_128x128 and tile(S, 6400, 1024, 2048) == _lib.TILE_128x64_S3
+    assert tile(B, 6400, 1024, 2048) == _lib.TILE_256x128_PP and tile(B, 3200, 2048, 1024) == _lib.TILE_256x128_PP      # thousands of rows: the ping-pong loop
+    assert tile(B, 6400, 1024, 1024, sched_fuse=1) == _lib.TILE_256x128_PP and tile(F, 6400, 1024, 1024, sched_fuse=1) == _lib.TILE_64x64
     assert tile(B, 2400, 1024, 1024) == _lib.TILE_80x128                # 30 x 8 = 240 tiles
     assert tile(B, 800, 1024, 1024, sched_fuse=1) == _lib.TILE_64x64 and tile(_lib.BF16X3, 1992, 2048, 1024) == _lib.TILE_64x64
     assert tile(B, 100, 1024, 1024, batch=8) == _lib.TILE_64x64
