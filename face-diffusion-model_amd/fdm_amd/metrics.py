@@ -90,6 +90,14 @@ def load_regions(region_path, dataset):
     return mouth, upper, 6172, [str(i) for i in range(46, 51)]
 
 
+def pred_name(subject, sentence, condition=None, model=""):
+    """Basename of a prediction file as computer_metrix.py reads it: `<subject>_<sentence>` (:74, what the MEAD / BIWI samplers
+    write), `<subject>_<sentence>_condition_<conditioning subject>` (:171-174, what samples/sample_diffusion_vocaset.py:86-88
+    writes), with `<model>_` in front when a model tag is given (:69-71)."""
+    name = subject + "_" + sentence + (("_condition_" + condition) if condition is not None else "")
+    return (model + "_" + name) if model != "" else name
+
+
 def evaluate(pred_path, gt_path, region_path, templates_path, train_subjects="F2 F3 F4 M3 M4 M5", model="", dataset="BIWI",
              device="cuda:0", verbose=True):
     """computer_metrix.py `main` (:6-136): same files, same naming, same printed lines; returns the numbers."""
@@ -101,7 +109,7 @@ def evaluate(pred_path, gt_path, region_path, templates_path, train_subjects="F2
     for subject in train_subjects.split(" "):
         for sentence in sentences:
             gt = np.load(os.path.join(gt_path, subject + "_" + sentence + ".npy")).reshape(-1, nv, 3)
-            name = (model + "_" + subject + "_" + sentence + "_condition_" + subject) if model != "" else (subject + "_" + sentence)
+            name = pred_name(subject, sentence, subject, model) if model != "" else pred_name(subject, sentence)
             pred = np.load(os.path.join(pred_path, name + ".npy")).reshape(-1, nv, 3)
             n = min(gt.shape[0], pred.shape[0])
             gt, pred = _dev(gt[:n], device), _dev(pred[:n], device)
@@ -125,11 +133,12 @@ def evaluate(pred_path, gt_path, region_path, templates_path, train_subjects="F2
     return res
 
 
-def diversity(pred_path, train_subjects, test_subjects, dataset="BIWI", device="cuda:0", verbose=True):
+def diversity(pred_path, train_subjects, test_subjects, dataset="BIWI", device="cuda:0", verbose=True, sentences=None, nr_vertices=None):
     """computer_metrix.py `compute_diversity` (:139-194): mean pairwise vertex distance between the predictions of one
-    test sequence under different conditioning subjects."""
-    nv = 23370 if dataset == "BIWI" else 6172
-    sentences = ["e" + str(i).zfill(2) for i in range(37, 41)] if dataset == "BIWI" else [str(i) for i in range(46, 51)]
+    test sequence under different conditioning subjects.  `sentences` / `nr_vertices` override the two tables the reference
+    hard-codes per dataset (:155-162), e.g. VOCASET's 5023-vertex meshes and `sentenceNN` names."""
+    nv = nr_vertices or (23370 if dataset == "BIWI" else 6172)
+    sentences = sentences or (["e" + str(i).zfill(2) for i in range(37, 41)] if dataset == "BIWI" else [str(i) for i in range(46, 51)])
     say = print if verbose else (lambda *a, **k: None)
     total, num = 0.0, 0
     for subject in test_subjects.split(" "):
@@ -137,7 +146,7 @@ def diversity(pred_path, train_subjects, test_subjects, dataset="BIWI", device="
             say(subject, sentence)
             seqs = []
             for cond in train_subjects.split(" "):
-                fp = os.path.join(pred_path, subject + "_" + sentence + "_condition_" + cond + ".npy")
+                fp = os.path.join(pred_path, pred_name(subject, sentence, cond) + ".npy")
                 if os.path.exists(fp):
                     seqs.append(_dev(np.load(fp).reshape(-1, nv, 3), device))
             n = len(seqs)

@@ -90,3 +90,28 @@ def test_metric_and_resampling_dropins_import_with_the_reference_names(dropin):
     from fdm_amd._lib import FdmError
     with pytest.raises(FdmError):      # no CPU fallback
         linear_interpolation(torch.zeros(1, 4, 4), 50, 30)
+
+
+def test_sampler_entry_points_and_file_names_match_what_the_metrics_read(dropin):
+    """The three named samplers exist (samples/sample_diffusion_{vocaset,mead,biwi}.py) and write the reference's file names:
+    VOCASET `<file>_condition_<conditioning subject>` (sample_diffusion_vocaset.py:61-62,86-88), MEAD / BIWI `<file>`
+    (sample_diffusion_mead.py:86, sample_diffusion_biwi.py:78) -- the names computer_metrix.py:69-74,171-174 (and the
+    evaluation drop-in, fdm_amd.metrics.pred_name) read back."""
+    import importlib.util
+    from fdm_amd import metrics
+    sd = os.path.join(DROPIN, "samples")
+    for ds in ("vocaset", "mead", "biwi"):
+        src = open(os.path.join(sd, f"sample_diffusion_{ds}.py")).read()
+        assert f'main("{ds}")' in src
+    spec = importlib.util.spec_from_file_location("sample_diffusion", os.path.join(sd, "sample_diffusion.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    conds = mod.CONDITION_SUBJECTS["vocaset"]
+    assert len(conds) == 8 and len(set(conds)) == 8 and all(c.startswith("FaceTalk_") and c.endswith("_TA") for c in conds)
+    subject, sentence = "FaceTalk_170809_00138_TA", "sentence21"
+    for i, c in enumerate(conds):
+        assert mod.save_name("vocaset", f"{subject}_{sentence}.wav", i) == metrics.pred_name(subject, sentence, c)
+    assert mod.save_name("biwi", "F1_e37.wav", 0) == metrics.pred_name("F1", "e37") == "F1_e37"
+    assert mod.save_name("mead", "M003_front_angry_level_3_001.wav", 0) == "M003_front_angry_level_3_001"
+    assert metrics.pred_name("F2", "e38", "F2", model="fdm") == "fdm_F2_e38_condition_F2"      # computer_metrix.py:69-71
+    assert mod.SHIPPED_DDIM_STEPS == {"vocaset": 100, "biwi": 50, "mead": None}

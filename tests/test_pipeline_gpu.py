@@ -128,18 +128,30 @@ def test_style_loop_batched_equals_the_reference_loop(tmp_path):
         calls["n"] += 1
         return orig(*a, **k)
     enc.forward = counting
+    # a VOCASET test-set file name: <subject>_<sentence>.wav
+    subject, sentence = "FaceTalk_170809_00138_TA", "sentence21"
     for mode, batched in (("batched", True), ("sequential", False)):
         calls["n"] = 0
-        mod.sample_step(mod.synthetic_loader(p, 1, 1.0), DEV, diffusion, ae, str(tmp_path / mode), p, 4, all_styles=True, batched=batched)
+        mod.sample_step(mod.synthetic_loader(p, 1, 1.0, names=[f"{subject}_{sentence}.wav"]), DEV, diffusion, ae, str(tmp_path / mode), p, 4,
+                        all_styles=True, batched=batched, dataset="vocaset")
         # batched: the audio encoder runs once per CLIP; the loop encodes once per call (the reference even re-encodes per step)
         assert calls["n"] == (1 if batched else p.n_style), f"{mode}: the audio encoder ran {calls['n']} times for one clip"
+    # the reference's file names: <file>_condition_<conditioning training subject> (samples/sample_diffusion_vocaset.py:61-62,86-88)
+    conds = mod.CONDITION_SUBJECTS["vocaset"]
+    assert len(conds) == p.n_style and conds[0] == "FaceTalk_170728_03272_TA" and conds[7] == "FaceTalk_170912_03278_TA"
     for it in range(p.n_style):
-        a = np.load(str(tmp_path / "batched" / f"synthetic_000_condition_{it}.npy"))
-        b = np.load(str(tmp_path / "sequential" / f"synthetic_000_condition_{it}.npy"))
+        a = np.load(str(tmp_path / "batched" / f"{subject}_{sentence}_condition_{conds[it]}.npy"))
+        b = np.load(str(tmp_path / "sequential" / f"{subject}_{sentence}_condition_{conds[it]}.npy"))
         assert a.shape == b.shape == (1, 48, 15069) and np.array_equal(a, b), it
-    a0 = np.load(str(tmp_path / "batched" / "synthetic_000_condition_0.npy"))
-    a5 = np.load(str(tmp_path / "batched" / "synthetic_000_condition_5.npy"))
+    a0 = np.load(str(tmp_path / "batched" / f"{subject}_{sentence}_condition_{conds[0]}.npy"))
+    a5 = np.load(str(tmp_path / "batched" / f"{subject}_{sentence}_condition_{conds[5]}.npy"))
     assert not np.array_equal(a0, a5)          # the style does change the animation
+    # ... which are the names the evaluation drop-in reads back (computer_metrix.py:171-174): the diversity metric runs on the
+    # sampler's output directory as it is
+    from fdm_amd import metrics
+    div = metrics.diversity(str(tmp_path / "batched"), " ".join(conds), subject, dataset="vocaset", device=DEV, verbose=False,
+                            sentences=[sentence], nr_vertices=5023)
+    assert np.isfinite(div) and div > 0
 
 
 def test_clips_of_different_lengths_batch_exactly():
