@@ -23,7 +23,6 @@
 // The causal + periodic-ALiBi bias of models/fdm_vocaset.py:95-116 is generated from (h, i, j)
 // in-kernel: no [H, 600, 600] mask tensor is ever read.
 #pragma once
-#include <algorithm>
 #include "common.hpp"
 #include "../../include/fdm_hip.h"
 
@@ -70,32 +69,12 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   // L2 instead of eight (FETCH_SIZE showed ~2.3x the algorithmic bytes with the plain (tile, head, clip) grid) -- and
   // the longest (last, causal) query tiles are dispatched first.
   const int L = p.L;
-  int b, h, q0;
-  if (p.xcd.n) {
-    // XCD-affine launch (fdm_attn_args.xcd): workgroup w serves row block w % 8 -- item w / 8 = (query tile of the block, head),
-    // heads fastest; the block's query tiles are counted clip by clip (cuts fall on multiples of 32 rows inside a clip, so a tile
-    // never straddles two blocks).  The context rows a workgroup writes are rows of its own block: the out-projection that reads
-    // them runs on the same XCD.
-    const int x = blockIdx.x & (FDM_XCD - 1), i = blockIdx.x >> 3;
-    const int r0 = p.xcd.row0[x], r1 = p.xcd.row0[x + 1];
-    h = i % p.H;
-    int j = i / p.H;
-    b = -1; q0 = 0;
-    for (int c = r0 / L; c * L < r1; ++c) {
-      const int s0 = max(r0, c * L) - c * L, s1 = min(r1, (c + 1) * L) - c * L;      // this clip's frames inside the block
-      const int nt = (s1 - s0 + BQ - 1) / BQ;
-      if (j < nt) { b = c; q0 = s0 + j * BQ; break; }
-      j -= nt;
-    }
-    if (b < 0) return;
-  } else {
-    const int nqt = (L + BQ - 1) / BQ;
-    const int grp = blockIdx.x / (8 * nqt), rem = blockIdx.x % (8 * nqt);
-    const int bh = grp * 8 + (rem & 7);
-    if (bh >= p.B * p.H) return;
-    b = bh / p.H; h = bh - b * p.H;
-    q0 = (nqt - 1 - (rem >> 3)) * BQ;
-  }
+  const int nqt = (L + BQ - 1) / BQ;
+  const int grp = blockIdx.x / (8 * nqt), rem = blockIdx.x % (8 * nqt);
+  const int bh = grp * 8 + (rem & 7);
+  if (bh >= p.B * p.H) return;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int q0 = (nqt - 1 - (rem >> 3)) * BQ;
   // (+4 floats per row: the merge writes below put 8 lanes on 8 consecutive rows at one column; without the pad they share
   //  a bank group -- SQ_LDS_BANK_CONFLICT was 79 % of this kernel's LDS cycles)
   __shared__ __attribute__((aligned(16))) float part_o[4][BQ][HD + 4];
@@ -343,18 +322,6 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   }
 }
 
-// workgroups of an XCD-affine launch: 8 x (query tiles x heads of the largest row block)
-static int attn_xcd_grid(const fdm_attn_args& a, int BQ) {
-  int mt = 0;
-  for (int x = 0; x < FDM_XCD; ++x) {
-    const int r0 = a.xcd.row0[x], r1 = a.xcd.row0[x + 1];
-    int nt = 0;
-    for (int c = r0 / a.L; c * a.L < r1; ++c) nt += (std::min(r1, (c + 1) * a.L) - std::max(r0, c * a.L) + BQ - 1) / BQ;
-    mt = std::max(mt, nt);
-  }
-  return FDM_XCD * mt * a.H;
-}
-
 template <typename T, int HD>
 static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   // two query sub-tiles per workgroup once the sequence is long enough that halving the K / V traffic matters more
@@ -363,12 +330,12 @@ static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   const int groups = (a.B * a.H + 7) / 8 * 8;        // (clip, head) pairs padded to whole XCD rounds
   if constexpr (HD <= 128 && Opnd<T>::NP == 1) {
     if (a.L >= qs2) {
-      dim3 grid(a.xcd.n ? attn_xcd_grid(a, 32) : (a.L + 31) / 32 * groups);
+      dim3 grid((a.L + 31) / 32 * groups);
       hipLaunchKernelGGL((attn_kernel<T, HD, 2>), grid, dim3(256), 0, s, a);
       return;
     }
   }
-  dim3 grid(a.xcd.n ? attn_xcd_grid(a, 16) : (a.L + 15) / 16 * groups);
+  dim3 grid((a.L + 15) / 16 * groups);
   hipLaunchKernelGGL((attn_kernel<T, HD, 1>), grid, dim3(256), 0, s, a);
 }
 

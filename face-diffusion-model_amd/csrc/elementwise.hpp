@@ -21,13 +21,7 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
   __shared__ float red[4][NV];
   constexpr int d = 256 * NV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int row = blockIdx.x;
-  if (p.xcd.n) {       // XCD-affine launch (fdm_ln_args.xcd): workgroup w normalises a row of block w % 8 -- the XCD that wrote it
-    const int x = blockIdx.x & (FDM_XCD - 1);
-    row = p.xcd.row0[x] + (blockIdx.x >> 3);
-    if (row >= p.xcd.row0[x + 1]) return;
-  }
-  const int col = tid * 4;
+  const int row = blockIdx.x, col = tid * 4;
   const bool two = p.gamma2 != nullptr;
   // every load of the kernel is requested before the first value is used: the row, the matrix addend and the affine vectors
   // go out at once, the table row one dependent scalar load (the device-side step word) later -- one memory latency in
@@ -88,11 +82,6 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
 template <typename T, bool HEAVY>
 static hipError_t ln_launch_h(const fdm_ln_args& a, hipStream_t s) {
   dim3 grid(a.M);
-  if (a.xcd.n) {
-    int mr = 0;
-    for (int x = 0; x < FDM_XCD; ++x) mr = std::max(mr, a.xcd.row0[x + 1] - a.xcd.row0[x]);
-    grid = dim3(FDM_XCD * mr);
-  }
   switch (a.d) {
     case 256: hipLaunchKernelGGL((ln_row_kernel<T, 1, HEAVY>), grid, dim3(64), 0, s, a); break;
     case 512: hipLaunchKernelGGL((ln_row_kernel<T, 2, HEAVY>), grid, dim3(128), 0, s, a); break;

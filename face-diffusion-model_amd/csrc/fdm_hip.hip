@@ -88,7 +88,6 @@ int fdm_version(void) { return 103; }      // 1.03: round 3 (fdm_audio_prepare_c
 int fdm_abi_struct_size(const char* name) {
   if (!name) return fdm::fail(FDM_ERR_ARG, "abi_struct_size: null name");
   const std::string n(name);
-  if (n == "fdm_xcd_map") return (int)sizeof(fdm_xcd_map);
   if (n == "fdm_sched_args") return (int)sizeof(fdm_sched_args);
   if (n == "fdm_gemm_args") return (int)sizeof(fdm_gemm_args);
   if (n == "fdm_attn_args") return (int)sizeof(fdm_attn_args);
@@ -105,36 +104,6 @@ int fdm_device_ok(void) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
-}
-
-// an XCD-affine map covers rows [0, M) with 8 non-decreasing cuts; align > 0: every cut is a multiple of `align` rows inside its clip of L rows
-static bool xcd_map_ok(const fdm_xcd_map& m, int M, int L = 0, int align = 0) {
-  if (m.n == 0) return true;
-  if (m.n != FDM_XCD || m.row0[0] != 0 || m.row0[FDM_XCD] != M) return false;
-  for (int x = 0; x < FDM_XCD; ++x) {
-    if (m.row0[x + 1] < m.row0[x]) return false;
-    if (align > 0 && L > 0 && (m.row0[x] % L) % align) return false;
-  }
-  return true;
-}
-
-int fdm_xcd_rows_host(int clips, int L, int align, fdm_xcd_map* out) {
-  if (!out || clips <= 0 || L <= 0 || align <= 0) return fail(FDM_ERR_ARG, "xcd_rows: bad argument");
-  const long long R = (long long)clips * L;
-  out->n = FDM_XCD;
-  out->row0[0] = 0;
-  out->row0[FDM_XCD] = (int)R;
-  for (int x = 1; x < FDM_XCD; ++x) {
-    // the admissible cut (clip start + a multiple of `align` rows, or a clip end) nearest to x / 8 of the rows
-    const long long tgt = R * x / FDM_XCD;
-    const long long c = tgt / L, off = tgt % L;
-    const long long lo = c * L + off / align * align;
-    const long long hi = std::min(c * L + (off / align + 1) * align, (c + 1) * L);
-    long long cut = (tgt - lo <= hi - tgt) ? lo : hi;
-    if (cut < out->row0[x - 1]) cut = out->row0[x - 1];
-    out->row0[x] = (int)cut;
-  }
-  return FDM_OK;
 }
 
 static bool gemm_act_heavy_host(int act) { return act == FDM_ACT_MISH || act == FDM_ACT_GELU_ERF || act == FDM_ACT_GELU_TANH; }
@@ -167,8 +136,6 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (a->rln_gamma && (!a->rln_beta || !a->resid)) return fail(FDM_ERR_ARG, "gemm: rln_gamma needs rln_beta and resid");
   if ((a->stat_out || a->ln_stat_in) && (a->batch > 1 || a->out_batch_stride)) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding is not batched");
   if (a->tile < 0 || a->tile > FDM_TILE_MAX) return fail(FDM_ERR_ARG, "gemm: unknown tile %d", a->tile);
-  if (!xcd_map_ok(a->xcd, a->M) || (a->xcd.n && (a->batch > 1 || a->tile == FDM_TILE_256x128_PP)))
-    return fail(FDM_ERR_ARG, "gemm: bad XCD row map (8 non-decreasing cuts over [0, M], batch 1, not the ping-pong tile)");
   if (a->sched_fuse) {
     const fdm_sched_args& sc = a->sched;
     if (sc.mode != 0 && sc.mode != 1) return fail(FDM_ERR_ARG, "gemm: fused scheduler supports mode 0 (DDPM) and 1 (DDIM)");
@@ -204,7 +171,6 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream) {
   if (a->ldq % epc || a->ldo % 4 || !aligned16(a->Q) || !aligned16(a->Kp) || !aligned16(a->Vp) || !aligned16(a->O))
     return fail(FDM_ERR_ARG, "attention: operands need 16-byte aligned rows");
   if (a->slopes && a->period <= 0) return fail(FDM_ERR_ARG, "attention: period must be positive");
-  if (!xcd_map_ok(a->xcd, a->B * a->L, a->L, 32)) return fail(FDM_ERR_ARG, "attention: bad XCD row map (cuts on multiples of 32 rows inside a clip)");
   fdm_attn_args c = *a;
   return submit([c](hipStream_t s) { return fdm::attn_launch(c, s); }, stream, "attention");
 }
@@ -230,7 +196,6 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
   if (a->add_mat_group < 0 || a->add_mat_wrap < 0 ||
       (a->add_mat_group > 0 && (a->add_mat_L <= 0 || a->add_mat_group % a->add_mat_L || (a->add_mat_wrap > 0 && a->add_mat_wrap % a->add_mat_group))))
     return fail(FDM_ERR_SHAPE, "layernorm: shared add_mat needs add_mat_L | add_mat_group | add_mat_wrap (got %d, %d, %d)", a->add_mat_L, a->add_mat_group, a->add_mat_wrap);
-  if (!xcd_map_ok(a->xcd, a->M)) return fail(FDM_ERR_ARG, "layernorm: bad XCD row map");
   fdm_ln_args c = *a;
   return submit([c](hipStream_t s) {
     switch (c.dtype) {

@@ -19,7 +19,6 @@
 //    by what the launch can need (SPEC: lean / packed K,V / LayerNorm fold; HEAVY: transcendental activations; SCHED: the
 //    fused scheduler update) and the general edge-handling kernel serves only the shapes that need it.
 #pragma once
-#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -78,10 +77,10 @@ template <int MI, int NI> struct EpiPre { f32x4 csv[NI], bv[NI], gmv[NI], btv[NI
 
 template <typename T, int BM, int BN, int WM, int WN, bool SCHED = false>
 __device__ __forceinline__ void gemm_epi_preload(const fdm_gemm_args& p, int m0, int n0, int z, int wm, int wn, int g, int r16,
-                                                 bool ln_capable, EpiPre<BM / WM / 16, BN / WN / 16>& e, int Mlim = -1) {
+                                                 bool ln_capable, EpiPre<BM / WM / 16, BN / WN / 16>& e) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   if constexpr (SCHED) e.sc = sched_coef_load(p.sched);     // k -> t -> table entries: three dependent loads, hidden by the k loop
-  const int M = Mlim < 0 ? p.M : Mlim, N = p.N;     // Mlim: first row past this tile's row block (XCD-affine launches), else the matrix
+  const int M = p.M, N = p.N;
   const bool use_ln = ln_capable && p.ln_stat_in;
   const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
   const size_t ocol = (size_t)z * p.out_batch_stride;
@@ -136,8 +135,7 @@ constexpr int GEMM_LEAN = 1, GEMM_KV = 2, GEMM_FOLD = 4;
 template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true, bool SCHED = false, int SPEC = 0>
 __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               const EpiPre<BM / WM / 16, BN / WN / 16>& e, int m0, int n0, int z,
-                                              int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr,
-                                              int Mlim = -1) {
+                                              int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   constexpr bool LEAN = (SPEC & GEMM_LEAN) != 0;
   constexpr bool KVC = !LEAN || (SPEC & GEMM_KV), FOLDC = !LEAN || (SPEC & GEMM_FOLD);     // capabilities compiled in
@@ -145,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   using KK = typename Opnd<T>::KV;    // operand kind of the packed K / V outputs (a plane pair for f16x3)
   using KV = typename Opnd<KK>::E;    // their element type
   constexpr int KNP = Opnd<KK>::NP;
-  const int M = Mlim < 0 ? p.M : Mlim, N = p.N;
+  const int M = p.M, N = p.N;
   // Whole-tile packed-V fast path: stage the tile transposed in LDS ([n][m], the ring is free after the k loop) and
   // store 16-byte runs of consecutive keys (one packed chunk each).  Needs the tile to lie entirely in the V columns
   // and clip boundaries on 16-byte multiples (L % (16 / sizeof(KV)) == 0); otherwise the per-element scatter is used.
@@ -376,7 +374,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) { s += comb[((size_t)(gq * 4 + f) * BM + t) * 2]; q += comb[((size_t)(gq * 4 + f) * BM + t) * 2 + 1]; }
-        float* so = p.stat_out + ((size_t)(n0 / 64 + gq) * p.M + (m0 + t)) * 2;
+        float* so = p.stat_out + ((size_t)(n0 / 64 + gq) * M + (m0 + t)) * 2;
         so[0] = s; so[1] = q;
       }
     }
@@ -397,10 +395,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// One output tile: rows [m0, min(m0 + BM, Mlim)), columns [n0, n0 + BN) of batch z.  Mlim = p.M for the plain 2-D grid; an
-// XCD-affine launch passes the end of the tile's row block (rows past it are neither stored nor, as clamped source rows, read).
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0>
-__device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int m0, const int n0, const int z, const int M, const bool first_wg) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
   using E = typename Opnd<T>::E;
   constexpr int NP = Opnd<T>::NP;                // operand planes (2 for the split kinds: hi, lo)
@@ -426,7 +422,7 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
 
   const int tid = threadIdx.x, lane = tid & 63;
-  if (p.incr_counter && tid == 0 && first_wg) {
+  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
     const int nv = *p.incr_counter + 1;
     *p.incr_counter = nv;
     if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
@@ -438,7 +434,9 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r16 = lane & 15;
-  const int N = p.N;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int M = p.M, N = p.N;
   const E* A = (const E*)p.A + (size_t)z * p.a_batch_stride;
   const E* W = (const E*)p.W + (size_t)z * p.w_batch_stride;
   const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);   // bytes hi plane -> lo plane
@@ -500,7 +498,7 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
     if (t < nk) issue(t);
   EpiPre<MI, NI> epre;
   constexpr bool FOLDC = !(SPEC & GEMM_LEAN) || (SPEC & GEMM_FOLD);
-  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre, M);
+  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
   if constexpr (FOLDC) gemm_load_rowstats<BM>(p, m0, rowstat);   // visible to every wave after the first barrier of the k loop
 
   // fragment (plane pl, k-step s) of tile row `row` in the stage at `base`: one ds_read_b128 through the XOR swizzle
@@ -585,33 +583,13 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
 #ifdef FDM_GEMM_STAMPS
   if (stamps && tid == 0) stamps[2] = wall_clock64();
 #endif
-  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem, M);
+  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 #ifdef FDM_GEMM_STAMPS
   if (stamps && tid == 0) stamps[3] = wall_clock64();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (stamps && tid == 0) stamps[4] = wall_clock64();
 #endif
-}
-
-// Plain launch: 2-D grid of tiles.  XCD-affine launch (fdm_gemm_args.xcd.n == 8, include/fdm_hip.h): a 1-D grid in which workgroup
-// w -- dealt round-robin over the 8 XCDs, so w % 8 names an XCD, the same physical one in every launch of a stream
-// (tools/xcd_probe.cpp) -- works on row block w % 8 only: tile w / 8 of that block, column tiles fastest.  Every kernel of a step
-// program uses the same map, so the rows a block's tiles read were written by the same XCD one launch earlier and the A operand
-// is served by the local L2.  A block's last row tile ends at the block's end, not at a multiple of BM.
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
-  if (p.xcd.n) {
-    const int x = blockIdx.x & (FDM_XCD - 1), i = blockIdx.x >> 3;
-    const int r0 = p.xcd.row0[x], r1 = p.xcd.row0[x + 1];
-    const int nct = (p.N + BN - 1) / BN, nrt = (r1 - r0 + BM - 1) / BM;
-    if (i >= nrt * nct) return;
-    const int rt = i / nct, ct = i - rt * nct;
-    gemm_glds_tile<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC>(p, r0 + rt * BM, ct * BN, blockIdx.z, r1, blockIdx.x == 0 && blockIdx.z == 0);
-  } else {
-    gemm_glds_tile<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC>(p, blockIdx.y * BM, blockIdx.x * BN, blockIdx.z, p.M,
-                                                                   blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -887,11 +865,6 @@ static hipError_t gemm_pp_launch_h(const fdm_gemm_args& a, hipStream_t s) {
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false, int SPEC = 0>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
-  if (a.xcd.n) {      // XCD-affine: 8 x (tiles of the largest row block)
-    int mt = 0;
-    for (int x = 0; x < FDM_XCD; ++x) mt = std::max(mt, (a.xcd.row0[x + 1] - a.xcd.row0[x] + BM - 1) / BM);
-    grid = dim3(FDM_XCD * mt * ((a.N + BN - 1) / BN), 1, a.batch > 0 ? a.batch : 1);
-  }
   constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
   static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
   static bool once = [] {
@@ -1057,7 +1030,6 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_256x128_PP: return gemm_pp_launch_t<T, 256, 128, 4, 2, 3>(a, s);   // ping-pong loop, 64x64 per wave, 146 KB
     case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);      // 8 waves, 80x16 per wave: 800 rows x 3072 = 240 workgroups
     case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4>(a, s);      // 8 waves, 32x32 per wave
-    case FDM_TILE_112x128: return gemm_glds_launch_t<T, 112, 128, 1, 8, 4>(a, s);    // 8 waves, 112x16 per wave, 120 KB: one XCD row block
     default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                    // FDM_TILE_64x64: 8 waves, 32x16 per wave
   }
 }
@@ -1085,7 +1057,6 @@ static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
       case FDM_TILE_256x128_PP: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);    // 128 KB, one tile in flight
       case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);      // 156 KB
       case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 3>(a, s);      // 144 KB
-      case FDM_TILE_112x128: return gemm_glds_launch_t<T, 112, 128, 1, 8, 2>(a, s);    // 120 KB, one tile in flight
       default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                    // FDM_TILE_64x64: 128 KB ring
     }
   }

@@ -23,10 +23,6 @@ class SchedArgs(C.Structure):
                 ("mode", ci), ("x_out_t_lo_off", ll), ("seed_dev", vp)]
 
 
-class XcdMap(C.Structure):
-    _fields_ = [("n", ci), ("row0", ci * 9)]
-
-
 class GemmArgs(C.Structure):
     _fields_ = [("A", vp), ("lda", ll), ("a_batch_stride", ll),
                 ("W", vp), ("ldw", ll), ("w_batch_stride", ll),
@@ -40,10 +36,10 @@ class GemmArgs(C.Structure):
                 ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
                 ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci),
                 ("sched_fuse", ci), ("sched", SchedArgs),
-                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll), ("xcd", XcdMap)]
+                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll)]
 
 
-TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP, TILE_80x128, TILE_64x128, TILE_112x128 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13
+TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP, TILE_80x128, TILE_64x128 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 
 
 class ModelDesc(C.Structure):
@@ -63,18 +59,18 @@ class VqDesc(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("Q", vp), ("ldq", ll), ("Kp", vp), ("Vp", vp), ("Lpad", ci),
                 ("O", vp), ("ldo", ll), ("B", ci), ("H", ci), ("L", ci), ("hd", ci), ("dtype", ci),
-                ("scale", cf), ("causal", ci), ("slopes", vp), ("period", ci), ("o_split", ci), ("o_lo_off", ll), ("q_lo_off", ll), ("kv_lo_off", ll), ("xcd", XcdMap)]
+                ("scale", cf), ("causal", ci), ("slopes", vp), ("period", ci), ("o_split", ci), ("o_lo_off", ll), ("q_lo_off", ll), ("kv_lo_off", ll)]
 
 
 class LnArgs(C.Structure):
     _fields_ = [("x", vp), ("M", ci), ("d", ci), ("add_mat", vp), ("add_tab", vp),
                 ("tab_index", vp), ("tab_step", vp), ("gamma", vp), ("beta", vp), ("eps", cf),
                 ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci), ("gamma2", vp), ("beta2", vp), ("y_t_lo_off", ll),
-                ("add_mat_L", ci), ("add_mat_group", ci), ("add_mat_wrap", ci), ("xcd", XcdMap)]
+                ("add_mat_L", ci), ("add_mat_group", ci), ("add_mat_wrap", ci)]
 
 
 # public structs of include/fdm_hip.h -> their mirrors (sizes checked against the loaded library in lib())
-STRUCTS = {"fdm_xcd_map": XcdMap, "fdm_sched_args": SchedArgs, "fdm_gemm_args": GemmArgs, "fdm_attn_args": AttnArgs, "fdm_ln_args": LnArgs,
+STRUCTS = {"fdm_sched_args": SchedArgs, "fdm_gemm_args": GemmArgs, "fdm_attn_args": AttnArgs, "fdm_ln_args": LnArgs,
            "fdm_model_desc": ModelDesc, "fdm_sample_args": SampleArgs, "fdm_vq_desc": VqDesc}
 
 # every symbol include/fdm_hip.h declares: name -> (restype, argtypes)
@@ -83,7 +79,6 @@ SYMBOLS = {
     "fdm_version": (ci, []),
     "fdm_abi_struct_size": (ci, [C.c_char_p]),
     "fdm_device_ok": (ci, []),
-    "fdm_xcd_rows_host": (ci, [ci, ci, ci, C.POINTER(XcdMap)]),
     "fdm_op_gemm": (ci, [C.POINTER(GemmArgs), vp]),
     "fdm_gemm_heuristic_tile": (ci, [C.POINTER(GemmArgs)]),
     "fdm_op_attention": (ci, [C.POINTER(AttnArgs), vp]),

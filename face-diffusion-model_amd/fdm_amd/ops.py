@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, BF16X3, F16X3, F32,
-                   AttnArgs, GemmArgs, LnArgs, SchedArgs, XcdMap, check, lib)
+                   AttnArgs, GemmArgs, LnArgs, SchedArgs, check, lib)
 
 
 class Split:
@@ -47,13 +47,6 @@ class Split:
         """hi + lo / SCALE as fp32 (tests)."""
         sc = 2048.0 if self.code == F16X3 else 1.0
         return (self.planes[0].float() + self.planes[1].float() / sc)[self.row0:]
-
-
-def xcd_rows(clips, L, align=32):
-    """Balanced XCD row map (include/fdm_hip.h, fdm_xcd_map) over clips * L rows, cuts on multiples of `align` rows inside a clip."""
-    m = XcdMap()
-    check(lib().fdm_xcd_rows_host(clips, L, align, C.byref(m)))
-    return m
 
 
 def _p(t):
@@ -95,7 +88,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
          out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
          out_kp=None, kp_col0=0, out_vp=None, vp_col0=0, kv_L=0, kv_Lpad=0, kv_hd=0,
          stat_out=None, ln_stat_in=None, ln_nparts=0, ln_dim=0, ln_eps=1e-5, ln_colsum=None, rln_gamma=None, rln_beta=None,
-         incr_counter=None, incr_table=None, tile=0, sched=None, xcd=None):
+         incr_counter=None, incr_table=None, tile=0, sched=None):
     a = GemmArgs()
     a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
     a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
@@ -115,8 +108,6 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.ln_colsum, a.rln_gamma, a.rln_beta = _p(ln_colsum), _p(rln_gamma), _p(rln_beta)
     a.incr_counter, a.incr_table = _p(incr_counter), _p(incr_table)
     a.tile = tile
-    if xcd is not None:
-        a.xcd = xcd
     if sched is not None:      # fused scheduler update in the epilogue (resid = x_t, out_f32 = x_{t-1})
         a.sched_fuse, a.sched = 1, sched
     check(lib().fdm_op_gemm(C.byref(a), stream()))
@@ -138,7 +129,7 @@ def pack_kv(K, V, Kp, Vp, *, B, H, L, Lpad, hd, ldk, ldv):
     check(lib().fdm_op_pack_kv(_p(K), ldk, _p(V), ldv, _p(Kp), _p(Vp), B, H, L, Lpad, hd, code_of(K), stream()))
 
 
-def attention(Q, Kp, Vp, O, *, B, H, L, hd, ldq, ldo, Lpad, scale, causal=False, slopes=None, period=1, xcd=None):
+def attention(Q, Kp, Vp, O, *, B, H, L, hd, ldq, ldo, Lpad, scale, causal=False, slopes=None, period=1):
     a = AttnArgs()
     a.Q, a.ldq, a.Kp, a.Vp, a.Lpad = _p(Q), ldq, _p(Kp), _p(Vp), Lpad
     a.O, a.ldo, a.B, a.H, a.L, a.hd, a.dtype = _p(O), ldo, B, H, L, hd, code_of(Q)
@@ -147,20 +138,16 @@ def attention(Q, Kp, Vp, O, *, B, H, L, hd, ldq, ldo, Lpad, scale, causal=False,
     elif isinstance(O, Split):     # fp32 attention writing the next GEMM's split operand
         a.o_split, a.o_lo_off = O.code, O.lo_off
     a.scale, a.causal, a.slopes, a.period = scale, int(causal), _p(slopes), period
-    if xcd is not None:
-        a.xcd = xcd
     check(lib().fdm_op_attention(C.byref(a), stream()))
 
 
 def layernorm(x, gamma, beta, M, d, *, add_mat=None, add_tab=None, tab_index=None, tab_step=None, eps=1e-5,
-              act=ACT_NONE, y_f32=None, y_t=None, dtype=F32, gamma2=None, beta2=None, xcd=None):
+              act=ACT_NONE, y_f32=None, y_t=None, dtype=F32, gamma2=None, beta2=None):
     a = LnArgs()
     a.x, a.M, a.d, a.add_mat, a.add_tab = _p(x), M, d, _p(add_mat), _p(add_tab)
     a.tab_index, a.tab_step, a.gamma, a.beta, a.eps = _p(tab_index), _p(tab_step), _p(gamma), _p(beta), eps
     a.act, a.y_f32, a.y_t, a.dtype = act, _p(y_f32), _p(y_t), dtype
     a.gamma2, a.beta2, a.y_t_lo_off = _p(gamma2), _p(beta2), _lo(y_t)
-    if xcd is not None:
-        a.xcd = xcd
     check(lib().fdm_op_layernorm(C.byref(a), stream()))
 
 

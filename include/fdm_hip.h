@@ -98,19 +98,6 @@ typedef struct fdm_sched_args {
 int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * XCD-affine launches (round 4).  MI355X deals the workgroups of a launch round-robin over its 8 XCDs, each with an L2 of its
- * own, and workgroup w of EVERY launch of a stream lands on the same physical XCD as workgroup w % 8 of the launch before
- * (measured: tools/xcd_probe.cpp).  A row-wise operator chain (GEMM -> LayerNorm -> GEMM -> attention ...) can therefore keep
- * each row on one XCD from kernel to kernel: the rows are cut into 8 contiguous blocks, block x = rows [row0[x], row0[x + 1]),
- * and in every operator given the same map the workgroups with id % 8 == x produce and consume block x only, so a consumer
- * finds its activation rows in the L2 its producer wrote them to.  n = 0: the operator's plain grid; n = 8: the map is used
- * (row0[0] = 0, row0[8] = M, non-decreasing).  Results never depend on the map (placement is a speed matter only).
- * fdm_xcd_rows_host fills a balanced map whose cuts fall on multiples of `align` rows inside every clip of L rows. */
-#define FDM_XCD 8
-typedef struct fdm_xcd_map { int n; int row0[FDM_XCD + 1]; } fdm_xcd_map;
-int fdm_xcd_rows_host(int clips, int L, int align, fdm_xcd_map* out);
-
-/* ------------------------------------------------------------------------------------------
  * C[M,N] = epilogue(A[M,K] * W[N,K]^T): every nn.Linear / Conv1d-as-GEMM on the path
  * (models/fdm_vocaset.py:20-24,36-39,45-51; transformers HubertAttention/FeedForward;
  * models/lib/base_models.py:71-87,138-174; models/vq_vae_vocaset.py:204,243).
@@ -166,7 +153,6 @@ typedef struct fdm_gemm_args {
   /* split operand kinds (dtype FDM_F16X3 / FDM_BF16X3): elements between the hi and lo planes of A, W and out_t */
   long long a_lo_off, w_lo_off, out_t_lo_off;
   long long kv_lo_off;            /* FDM_F16X3 with out_kp / out_vp: elements between the hi and lo planes of the packed buffers */
-  fdm_xcd_map xcd;                /* XCD-affine launch (above); batch must be 1; not with FDM_TILE_256x128_PP */
 } fdm_gemm_args;
 #define FDM_TILE_AUTO 0
 #define FDM_TILE_64x64 1
@@ -181,8 +167,7 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_256x128_PP 10 /* 256x128, two wave groups half a period apart (one computes while the other loads): large M */
 #define FDM_TILE_80x128 11     /* 80x128: ten row tiles for 800 rows -> 240 workgroups at N = 3072 (the QKV projection of four 200-frame clips) */
 #define FDM_TILE_64x128 12     /* 64x128: 13 row tiles for 800 rows -> 208 workgroups at N = 2048 in one round (FFN1 in the split modes) */
-#define FDM_TILE_112x128 13    /* 112x128: a ~100-row XCD block x 24 column tiles of a QKV projection (XCD-affine launches) */
-#define FDM_TILE_MAX 13
+#define FDM_TILE_MAX 12
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 /* The FDM_TILE_* value a launch of *a with tile = 0 resolves to (the library heuristic on M, N, K, batch and the operand kind;
  * no device work, a->tile is ignored).  The plan-time tuner uses it to leave the heuristic's own tile out of its candidates. */
@@ -222,7 +207,6 @@ typedef struct fdm_attn_args {
    * 16-bit MFMA passes with the probabilities split in registers: fp32-class results.  q_lo_off / kv_lo_off / o_lo_off =
    * elements between the hi and lo planes of Q / Kp and Vp / O. */
   long long q_lo_off, kv_lo_off;
-  fdm_xcd_map xcd;       /* XCD-affine launch: rows are b * L + l; every cut of the map must fall on a multiple of 32 rows inside its clip */
 } fdm_attn_args;
 int fdm_op_attention(const fdm_attn_args* a, void* stream);
 /* row-major K, V (row b*L + l, column h*hd + e, row strides ldk / ldv) -> the packed layouts above */
@@ -253,7 +237,6 @@ typedef struct fdm_ln_args {
    * (add_mat_group = S * L, add_mat_L = L, add_mat_wrap = rows per cond/uncond half, 0 = no wrap) over an add_mat of
    * [clips * L, d]; 0 = row m reads add_mat row m */
   int add_mat_L, add_mat_group, add_mat_wrap;
-  fdm_xcd_map xcd;                    /* XCD-affine launch: workgroup w normalises row row0[w % 8] + w / 8 */
 } fdm_ln_args;
 int fdm_op_layernorm(const fdm_ln_args* a, void* stream);
 

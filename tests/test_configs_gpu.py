@@ -21,13 +21,44 @@ from oracle import weights as W  # noqa: E402
 
 DEV = "cuda:0"
 TOL = 1e-4
+# bf16 (BASELINE configs name it; outside the 1e-4 contract by construction): stated bar = 2x the distance measured on MI355X
+# (round 4, printed by the tests below with -s) over the first steps of each chain -- at t = 999.. the update coefficients are tiny
+BF16_FIRST_STEPS_BAR = {"cfg2": 1e-2, "cfg3": 1e-2, "cfg4": 1e-2}
 
 
 def mad(a, b):
     return float((torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
 
 
-@pytest.mark.parametrize("dtype", [F32, F16X3])
+def _bar(dtype, cfg):
+    return BF16_FIRST_STEPS_BAR[cfg] if dtype == BF16 else TOL
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
+def test_cfg2_first_steps_vs_oracle(dtype):
+    """cfg2 at its benched shape (VOCASET, 4 clips x 200 frames, DDPM): the first 3 steps (t = 999, 998, 997; injected noise) of
+    clips 0 and 3 against the CPU oracle, in every mode bench.py times."""
+    preset, B, L, T = "vocaset", 4, 200, 1000
+    w = W.make_fdm_weights(preset)
+    inp = W.synth_inputs(preset, B, L, seed=2)
+    plan = DenoiserPlan(preset, w, dtype, DEV)
+    plan.prepare(inp["hub"], inp["style"], L=L)
+    ts = list(range(T - 1, -1, -1))
+    k = 3
+    noise = torch.randn(k, *inp["x"].shape, generator=torch.Generator().manual_seed(0))
+    rec = []
+    plan.sample_ddpm(inp["x"].to(DEV), ts[:k], noise=noise, record=rec)
+    worst = 0.0
+    for b in (0, 3):
+        den = lambda x, t: FO.fdm_forward(w, preset, inp["hub"][b:b + 1], t, x, inp["style"][b:b + 1], None, folded=True)
+        ref = []
+        FO.p_sample_loop(den, inp["x"][b:b + 1].clone(), noise[:, b:b + 1], ts[:k], record=ref)
+        worst = max(worst, mad(torch.stack(rec)[:, b:b + 1], torch.stack(ref)))
+    print(f"[cfg2 dtype {dtype}] first {k} steps vs oracle: max-abs {worst:.3e} (bar {_bar(dtype, 'cfg2'):.1e})")
+    assert worst < _bar(dtype, "cfg2")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
 def test_cfg3_mead_full_chain_with_guidance(dtype):
     preset, B, L, T = "mead", 4, 300, 1000
     w = W.make_fdm_weights(preset)
@@ -44,7 +75,9 @@ def test_cfg3_mead_full_chain_with_guidance(dtype):
     den = lambda x, t: FO.fdm_forward_cfg(w, preset, inp["hub"][1:2], t, x, inp["style"][1:2], inp["emo"][1:2], 2.5, folded=True)
     ref = []
     FO.p_sample_loop(den, inp["x"][1:2].clone(), noise[:, 1:2], ts[:k], record=ref)
-    assert mad(torch.stack(rec)[:, 1:2], torch.stack(ref)) < TOL
+    dist = mad(torch.stack(rec)[:, 1:2], torch.stack(ref))
+    print(f"[cfg3 dtype {dtype}] first {k} steps vs oracle: max-abs {dist:.3e} (bar {_bar(dtype, 'cfg3'):.1e})")
+    assert dist < _bar(dtype, "cfg3")
     # full chain: determinism, finiteness, clip independence under CFG
     a = plan.sample_ddpm(xT, ts, seed=9, cfg_scale=2.5)
     assert a.shape == (B, L * 8, 64) and torch.isfinite(a).all()
@@ -54,7 +87,7 @@ def test_cfg3_mead_full_chain_with_guidance(dtype):
     assert torch.equal(one[0], a[2]), "clip result depends on the batch it was sampled in"
 
 
-@pytest.mark.parametrize("dtype", [F32, F16X3])
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
 def test_cfg4_biwi_full_ddim_chain(dtype):
     from test_denoiser_gpu import _biwi_oracle_clip
     preset, B, L, steps = "biwi", 4, 200, 250
@@ -76,7 +109,9 @@ def test_cfg4_biwi_full_ddim_chain(dtype):
     for i, (t, tn) in enumerate(pairs[:2]):
         x0 = _biwi_oracle_clip(w, hub[3].reshape(L, 1536), t, x, inp["style"][3])
         x = FO.ddim_step(buf, x0, x, t, tn)
-        assert mad(rec[i][3], x) < TOL, (i, t)
+        dist = mad(rec[i][3], x)
+        print(f"[cfg4 dtype {dtype}] live pair {i} (t = {t}) vs oracle: max-abs {dist:.3e} (bar {_bar(dtype, 'cfg4'):.1e})")
+        assert dist < _bar(dtype, "cfg4"), (i, t)
     # properties over the whole 249-call chain
     assert torch.equal(a, plan.sample_ddim(xT, steps)), "not deterministic"
     assert torch.equal(a, plan.sample_ddim(xT, steps, graph_steps=1)), "steps per graph launch changed the result"

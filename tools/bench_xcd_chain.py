@@ -5,6 +5,8 @@ and with the XCD-affine row map (fdm_xcd_map: every kernel's workgroup w works o
   A. 12 x {out-proj-shaped GEMM 64x64 (+bias, +fp32 residual, fp32 + operand outputs) -> LayerNorm}   (the review's probe)
   B. 8 decoder layers {QKV -> attention -> out-proj -> LN1+LN2 -> FFN1 -> FFN2 -> LN3} with 8 distinct weight sets
 Outputs of the two forms are compared bit for bit.   python tools/bench_xcd_chain.py [bf16|f16x3]
+Needs the library of commit e27fd28 (fdm_xcd_map in the operator argument structs): the maps were measured and removed again
+(profiles/README.md, round 4; results in profiles/r4_xcd_affinity/).
 """
 import math
 import sys
@@ -18,6 +20,7 @@ from bench_ops import timeit
 
 DEV = 'cuda:0'
 mode = sys.argv[1] if len(sys.argv) > 1 else 'bf16'
+only = int(sys.argv[2]) if len(sys.argv) > 2 else -1      # profiling: run variant `only` of chain B alone (rocprofv3 --kernel-trace --stats)
 code = {'bf16': BF16, 'f16x3': F16X3}[mode]
 B, L, d, H, ffn = 4, 200, 1024, 8, 2048
 M, hd = B * L, 128
@@ -57,14 +60,14 @@ def reset():
 
 
 res = {}
-for name, xcd in (("plain", None), ("xcd-affine", xmap)):
+for name, xcd in (("plain", None), ("xcd-affine", xmap)) if only < 0 else ():
     reset(); chain_a(xcd); torch.cuda.synchronize(); res[name] = h.clone()
     us = timeit(lambda: chain_a(xcd), n_rec=1, reps=50)
     print(f"A. {mode} 12 x (GEMM 64x64 + LayerNorm), {name:10s}: {us / NW:7.2f} us per pair")
-print("A. bit-identical:", bool(torch.equal(res["plain"], res["xcd-affine"])))
+if only < 0: print("A. bit-identical:", bool(torch.equal(res["plain"], res["xcd-affine"])))
 # the GEMM alone in the chain: the same chain with the LayerNorm replaced by nothing is not a dependent chain of fresh operands,
 # so time GEMM and LN shares by leaving one out of the replay with the other still producing its operand
-for name, xcd in (("plain", None), ("xcd-affine", xmap)):
+for name, xcd in (("plain", None), ("xcd-affine", xmap)) if only < 0 else ():
     def only_ln():
         for i in range(NW): ops.layernorm(x1, g1, b1, M, d, y_f32=h, y_t=ht, dtype=code, xcd=xcd)
     print(f"A. {mode} LayerNorm alone x 12, {name:10s}: {timeit(only_ln, n_rec=1, reps=50) / NW:7.2f} us each")
@@ -105,7 +108,7 @@ variants = [("plain grids, the step's tiles (80x128, 64x64, 64x64)", None, TILE_
             ("xcd-affine (112x128, 64x64, 64x64)", xmap, TILE_112x128, TILE_64x64),
             ("plain grids, the affine tiles (112x128, 64x64, 64x128)", None, TILE_112x128, TILE_64x128)]
 ref = None
-for name, xcd, tq, tf in variants:
+for name, xcd, tq, tf in (variants if only < 0 else variants[only:only + 1]):
     reset(); layers(xcd, tq, tf); torch.cuda.synchronize()
     out = h.clone()
     if ref is None: ref = out
