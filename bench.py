@@ -20,6 +20,16 @@ BASELINE.json configs[1]):
 --config cfg1x8 is the reference sampler's style loop (samples/sample_diffusion_vocaset.py:71-83: 1 clip x 100 frames x 8 style
 one-hots, DDIM 100) as ONE condition-batched call, reported beside the sequential loop of eight B = 1 calls.
 
+--config shipped_vocaset | shipped_mead | shipped_biwi is what the reference's OWN callers issue for one test clip, end to end
+inside the timed call (samples/sample_diffusion_vocaset.py:71-88: 10 s of audio -> HuBERT-large -> every one of the 8 style
+one-hots, DDIM 100 -> quant -> decode; sample_diffusion_mead.py:67-86: HuBERT -> 1000-step DDPM -> EVQ quant -> decode;
+sample_diffusion_biwi.py:60-78: wav2vec2-base -> DDIM 50 -> quant -> decode to 23370 vertices), with a per-stage split
+("stages_ms") and, for VOCASET, the reference's sequential loop of eight B = 1 pipelines beside the condition-batched call.
+
+roofline_hbm: the HBM-class kernels of the step (SURVEY.md section 8d "report both per kernel class"): the LayerNorm launches and the
+scheduler-fused latent decoder's epilogue traffic, algorithmic bytes / profiled duration (the committed rocprofv3 summary of this
+configuration and mode) / 8 TB/s.
+
 roofline: the dominant launch is the captured step graph (one diffusion step).  achieved =
 algorithmic FLOPs per diffusion step (2*[B*L*(2d^2 + n_layers*(4d^2 + 2*d*FFN)) +
 n_layers*B*2*L^2*d]) / average step duration from HIP events recorded on the plan's stream around the
@@ -52,7 +62,15 @@ CONFIGS = {
     # the reference sampler's own loop: every style one-hot of a clip, same audio (samples/sample_diffusion_vocaset.py:71-83)
     "cfg1x8": ("vocaset", 1, 100, 100, "ddim", False),
 }
-CONDS = {"cfg1x8": 8}
+CONDS = {"cfg1x8": 8, "shipped_vocaset": 8}
+# what the reference's samplers issue per test clip: (preset, audio seconds, latent frames, diffusion steps, sampler, audio encoder)
+SHIPPED = {
+    "shipped_vocaset": ("vocaset", 10.0, 498, 100, "ddim", "hubert"),     # L = HuBERT frames (samples/sample_diffusion_vocaset.py:76)
+    "shipped_mead": ("mead", 10.0, 249, 1000, "ddpm", "hubert"),          # L = HuBERT frames // 2 (sample_diffusion_mead.py:79)
+    "shipped_biwi": ("biwi", 10.0, 240, 50, "ddim", "wav2vec"),           # L = int(seconds * 24) (sample_diffusion_biwi.py:69)
+}
+for _k, (_p, _s, _L, _T, _smp, _enc) in SHIPPED.items():
+    CONFIGS[_k] = (_p, 1, _L, _T, _smp, False)
 # dense TFLOP/s, MI355X_MICROARCH.md.  The split modes run on the 16-bit matrix cores (3 MFMA passes per product) and are
 # priced against that peak with the ALGORITHMIC flops (one product per multiply-add), like every other mode.
 PEAK = {"bf16": 2500.0, "f32": 157.3, "f16x3": 2500.0, "bf16x3": 2500.0}
@@ -119,6 +137,37 @@ def cpu_baseline(cfg_name, budget_s=24.0):
                       f"re-run in every step, full cross-attention): 1 clip of 1 step timed x{B} clips = "
                       f"{per_step_aw * 1e3:.0f} ms/step -> {B * L / (per_step_aw * T):.4f} frames/s",
             "as_written_value": round(B * L / (per_step_aw * T), 5)}
+
+
+def hbm_class_roofline(pm, rel, p, rows, dtype_name):
+    """HBM-class entries from a committed profile summary (tools/pmc_report.py): algorithmic bytes per launch / profiled us / 8 TB/s.
+    LayerNorm (fdm_amd csrc/elementwise.hpp ln_row_kernel): the fused LN1+LN2 launch reads the fp32 row and the per-clip addend and
+    writes the fp32 row + the operand copy, LN3 reads one and writes the two -- (8 + 2 x 4 + 2 x ob) / 2 bytes per element on
+    average, ob = bytes of the operand copy (2 for bf16, 4 for a split-fp16 plane pair).  Scheduler update fused into the latent
+    decoder's epilogue: 16 B per latent element (3 fp32 reads + 1 write) -- that launch is a GEMM, so its entry
+    states the epilogue's share of HBM-class bytes next to the whole launch's duration (an upper bound on the time it can cost)."""
+    ob = {"bf16": 2, "f32": 0, "f16x3": 4, "bf16x3": 4}[dtype_name]
+    n = rows * p.d
+    out = []
+    ln = [k for k in pm["kernels"] if "ln_row_kernel" in k["kernel"]]
+    if ln:
+        k = ln[0]
+        b = n * ((4 + 4 + 4 + ob) + (4 + 4 + ob)) / 2.0
+        gbs = b / (k["avg_us"] * 1e-6) / 1e9
+        out.append({"kernel": "LayerNorm launches (fused LN1+LN2 with the folded cross-attention addend; LN3)", "launches_per_step": k["launches_per_step"],
+                    "algorithmic_bytes_per_launch": int(b), "avg_us_profiled": k["avg_us"], "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4),
+                    "counter_bytes_per_launch": int((k.get("fetch_mb", 0) + k.get("write_mb", 0)) * 1024 * 1024) or None})
+    dec = [k for k in pm["kernels"] if "gemm" in k["kernel"] and "true, 1>" in k["kernel"].replace(" ", " ") and "false, true" in k["kernel"]]
+    if dec:
+        k = dec[0]
+        b = n * 16.0
+        out.append({"kernel": "scheduler update in the latent decoder's GEMM epilogue", "launches_per_step": k["launches_per_step"],
+                    "algorithmic_bytes_per_launch": int(b), "avg_us_profiled": k["avg_us"],
+                    "achieved": round(b / (k["avg_us"] * 1e-6) / 1e9, 1), "frac": round(b / (k["avg_us"] * 1e-6) / 1e9 / 8000.0, 4),
+                    "note": "duration of the whole GEMM launch (the plain 64x64 GEMM of the same shape takes "
+                            + str(next((q["avg_us"] for q in pm["kernels"] if "gemm" in q["kernel"] and "false, false, 1>" in q["kernel"] and q["grid"] == k["grid"]), None))
+                            + " us): the update rides an MFMA-class kernel"})
+    return {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "counters_from": rel, "kernels": out} if out else None
 
 
 PARITY_TOL = {"f32": 1e-4, "f16x3": 1e-4, "bf16": 0.15, "bf16x3": 1e-3}     # the bars tests/test_denoiser_gpu.py states per mode
@@ -210,7 +259,11 @@ def main():
     if S > 1:                                               # every style one-hot of each clip; all conditions start from the clip's x_T
         style = torch.eye(p.n_style)[:S].repeat(B, 1)
         xT = xT.repeat_interleave(S, dim=0)
-    e2e = a.config == "cfg5"
+    shipped = SHIPPED.get(a.config)                         # the reference callers' per-clip workload, end to end
+    e2e = a.config == "cfg5" or shipped is not None
+    if shipped:
+        style = torch.eye(p.n_style)[:S].repeat(B, 1) if S > 1 else torch.eye(p.n_style)[:1].repeat(B, 1)
+        emo = torch.eye(p.n_emo)[4:5].repeat(B, 1) if p.n_emo else None      # the demos' default emotion
     ts = list(range(T - 1, -1, -1))
     n_live = T if sampler == "ddpm" else T - 1              # denoiser calls per sampling call (DDIM: the dead pair is skipped)
 
@@ -252,32 +305,50 @@ def main():
         plan = DenoiserPlan(preset, weights, dt, dev)
         hub_plan = vq_plan = wav = None
         if e2e:
-            from fdm_amd.hubert import HubertPlan
+            from fdm_amd.hubert import WAV2VEC2_BASE, HubertPlan
             from fdm_amd.vq import VQPlan
             side_dt = dt if dt in (F32, DTYPE_NAMES["bf16"]) else F32     # VQ quant / decode run fp32 in the split modes (wider parity margin)
             hub_dt = dt if dt in (F32, DTYPE_NAMES["bf16"], DTYPE_NAMES["f16x3"]) else F32      # HuBERT: fp32, bf16, or split-fp16 layers
-            hub_plan = HubertPlan(W.make_hubert_weights(24), 24, hub_dt, dev)
+            if shipped and shipped[5] == "wav2vec":
+                hub_plan = HubertPlan(W.make_wav2vec_weights(12), 12, hub_dt, dev, cfg=WAV2VEC2_BASE)
+            else:
+                hub_plan = HubertPlan(W.make_hubert_weights(24), 24, hub_dt, dev)
             vq_plan = VQPlan(preset, W.make_vq_weights(preset), side_dt, dev)
             g = torch.Generator().manual_seed(100 + rank)
-            wav = (torch.randn(B, 160000, generator=g) * 0.1).to(dev)
+            wav = (torch.randn(B, int(shipped[1] * 16000) if shipped else 160000, generator=g) * 0.1).to(dev)
+        emo_b = emo                                          # [B*S] rows for the batched call (None where the preset has none)
+        emo_clip = None if emo is None else emo[:B]          # one row per clip: the codebook slice of the EVQ quantiser
 
-        def prep():
+        def prep(marks=None):
             if e2e:
-                plan.prepare(hub_plan.forward(wav), style, None, L=L)
+                feat = hub_plan.forward(wav)
+                if marks is not None:
+                    marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
+                plan.prepare(feat[:, :L * p.pair], style, emo_b, L=L, n_conds=S)
             else:
                 plan.prepare(hub, style, emo, L=L, cfg=cfg, n_conds=S)
         prep()
         plan.tune()        # plan-time work, outside the timed region: GEMM tile tuning for this shape (cached in the plan)
 
-        def one_call(collect=True):
-            if e2e or S > 1:   # per-clip work inside the call: HuBERT + tables (cfg5); the clip's tables for its S conditions (cfg1x8)
-                prep()
+        def one_call(collect=True, marks=None):
+            """marks (a list): HIP events after every stage of the call -- start, audio encoder, tables, chain, quant, decode"""
+            def mark():
+                if marks is not None:
+                    marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record()
+            mark()
+            if e2e or S > 1:   # per-clip work inside the call: HuBERT + tables (cfg5, shipped_*); the clip's tables for its S conditions (cfg1x8)
+                prep(marks)
+            mark()
             if sampler == "ddpm":
                 out = plan.sample_ddpm(xT, ts, seed=1234, clip0=rank * B * S)
             else:
                 out = plan.sample_ddim(xT, T)
+            mark()
             if e2e and not a.profile_steps:      # (counter profiles of the step graph end with the chain)
-                out = vq_plan.decode(vq_plan.quant(out * (1.5 / 1024))[0])
+                zq = vq_plan.quant(out * (1.5 / 1024), None if emo_clip is None else emo_clip.repeat_interleave(S, dim=0))[0]
+                mark()
+                out = vq_plan.decode(zq)
+                mark()
             return gather_clips(out, dist, sizes=[B * S] * world) if collect else out     # equal shards: no size exchange
 
         el, ev_ms, out = timed(one_call, steps, warmup)
@@ -296,7 +367,47 @@ def main():
                             "achieved": round(ach, 2), "peak": PEAK[dtype_name], "unit": "TFLOP/s",
                             "frac": round(ach / PEAK[dtype_name], 4), "traffic": None,
                             "flops_per_launch": fl, "avg_launch_ms": round(step_ms, 5)}}
-        if S > 1 and not a.profile_steps:
+        if shipped and not a.profile_steps:
+            # per-stage split of the call (HIP events between the stages, three extra calls outside the timed region)
+            acc = [0.0] * 5
+            for _ in range(3):
+                marks = []
+                one_call(False, marks)
+                torch.cuda.synchronize()
+                for i in range(5):
+                    acc[i] += marks[i].elapsed_time(marks[i + 1]) / 3.0
+            leg["stages_ms"] = {"audio_encoder": round(acc[0], 3), "tables": round(acc[1], 3), f"chain_{n_live}_denoiser_calls": round(acc[2], 3),
+                                "quant": round(acc[3], 3), "decode": round(acc[4], 3), "sum": round(sum(acc), 3)}
+            # the step graph's roofline entry from the chain stage alone (the call also holds the once-per-clip stages)
+            step_ms = acc[2] / n_live
+            ach = fl / (step_ms * 1e-3) / 1e12
+            leg["roofline"].update({"achieved": round(ach, 2), "frac": round(ach / PEAK[dtype_name], 4), "avg_launch_ms": round(step_ms, 5)})
+            leg["diffusion_steps_per_s"] = round(n_live / (acc[2] * 1e-3), 1)
+        if shipped and S > 1 and not a.profile_steps:
+            # the reference's loop as written (samples/sample_diffusion_vocaset.py:71-88): per style one-hot, one B = 1 pipeline --
+            # audio encoder, tables, DDIM chain, quant, decode -- with the same audio
+            st1 = [style[i:i + 1] for i in range(B * S)]
+
+            def seq_pipeline(collect=True):
+                outs = []
+                for r in range(B * S):
+                    feat = hub_plan.forward(wav)
+                    plan.prepare(feat[:, :L * p.pair], st1[r], emo_clip, L=L)
+                    lat = plan.sample_ddim(xT[r:r + 1], T) if sampler == "ddim" else plan.sample_ddpm(xT[r:r + 1], ts, seed=1234, clip0=r)
+                    outs.append(vq_plan.decode(vq_plan.quant(lat * (1.5 / 1024), emo_clip)[0]))
+                o = torch.cat(outs)
+                return gather_clips(o, dist, sizes=[B * S] * world) if collect else o
+            plan.prepare(hub_plan.forward(wav)[:, :L * p.pair], st1[0], emo_clip, L=L)
+            plan.tune()
+            el_s, ev_s, out_s = timed(seq_pipeline, steps, warmup)
+            leg["sequential_loop"] = {"value": round(world * B * S * L * steps / el_s, 3), "unit": "frames/s",
+                                      "ms_per_step": round(el_s / steps * 1e3, 3),
+                                      "what": f"{S} sequential B = 1 pipelines per clip (audio encoder + tables + chain + quant + decode each: "
+                                              "samples/sample_diffusion_vocaset.py:71-88)",
+                                      "bit_identical_to_batched": bool(torch.equal(out_s, out))}
+            leg["speedup_vs_sequential_loop"] = round(el_s / el, 3)
+            prep()
+        elif S > 1 and not a.profile_steps:
             # the reference's own loop: one B = 1 sampling call per style, same audio (tables rebuilt per call, as a caller that
             # loops ddim_sample does); same plan, same tiles policy, same timing harness
             st1 = [style[i:i + 1] for i in range(B * S)]
@@ -367,7 +478,7 @@ def main():
             r.update({"mfma_busy": None, "dominant_kernel": None, "counters_from": None, "counters_tiles": None, "counters_tiles_match": None})
             if a.batch:
                 return
-            for rd in ("r3", "r2"):
+            for rd in ("r4", "r3", "r2"):
                 try:
                     rel = f"profiles/{rd}_pmc_{a.config}_{leg['dtype']}/summary.json"
                     pm = json.load(open(os.path.join(ROOT, rel)))
@@ -379,6 +490,7 @@ def main():
                     r["counters_from"] = rel
                     r["counters_tiles"] = prof_tiles
                     r["counters_tiles_match"] = prof_tiles == leg["gemm_tiles"]
+                    leg["roofline_hbm"] = hbm_class_roofline(pm, rel, p, B * S * L * (2 if cfg else 1), leg["dtype"])
                     ks = [k for k in pm["kernels"] if "gemm" in k["kernel"]]
                     same_sites = all(prof_tiles.get(site, 0) == leg["gemm_tiles"].get(site, 0) for site in ("out", "ffn2"))
                     if ks and same_sites:
@@ -398,7 +510,10 @@ def main():
             "config": {"workload": f"{a.config}: {preset} FDM, {B} clips/GPU x {L} latent frames"
                                    + (f" x {S} style conditions per clip in one step program" if S > 1 else "")
                                    + f", {T}-step {sampler.upper()}{' + CFG 2.5' if cfg else ''}, random-init weights, "
-                                   + ("10 s synthetic audio -> HuBERT-large -> sample -> VQ quant + decode to 5023-vertex meshes"
+                                   + ((f"{shipped[1]:g} s synthetic audio -> {'wav2vec2-base' if shipped[5] == 'wav2vec' else 'HuBERT-large'} -> tables -> sample -> "
+                                       f"{'EVQ ' if p.n_emo else ''}quant -> decode to {p.V3 // 3}-vertex meshes, all inside the timed call (the reference's "
+                                       f"samples/sample_diffusion_{'vocaset' if preset == 'vocaset' else preset}.py per test clip)") if shipped else
+                                      "10 s synthetic audio -> HuBERT-large -> sample -> VQ quant + decode to 5023-vertex meshes"
                                       if e2e else "synthetic audio-encoder features, Philox noise"), "global_batch": B * world,
                        "latent_frames": L, "diffusion_steps": T, "parallelism": f"clip-shard x{world}"},
             "rccl_ranks": (dist.get_world_size() if dist is not None else 1),
@@ -411,7 +526,7 @@ def main():
             "gemm_tiles": head["gemm_tiles"],
             "roofline": head["roofline"],
         }
-        for k in ("sequential_loop", "speedup_vs_sequential_loop", "shard_check"):
+        for k in ("roofline_hbm", "stages_ms", "sequential_loop", "speedup_vs_sequential_loop", "shard_check"):
             if k in head:
                 res[k] = head[k]
         if "parity_max_abs" in head:
@@ -427,7 +542,7 @@ def main():
                                     "what": "the same workload in the arithmetic mode that meets north_star's 1e-4 max-abs tolerance"}
         if not a.no_cpu_baseline and world == 1:
             # the bounded CPU sample is defined for the denoiser-only configs; cfg4/cfg5 reuse cfg2's shape class
-            res["cpu_baseline"] = cpu_baseline(a.config if a.config in ("cfg1", "cfg2", "cfg3") else ("cfg1" if a.config == "cfg1x8" else "cfg2"))
+            res["cpu_baseline"] = cpu_baseline(a.config if a.config in ("cfg1", "cfg2", "cfg3") else ("cfg1" if (a.config == "cfg1x8" or shipped) else "cfg2"))
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()

@@ -326,7 +326,7 @@ template <typename T, int HD>
 static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   // two query sub-tiles per workgroup once the sequence is long enough that halving the K / V traffic matters more
   // than the number of workgroups; head_dim 256 and the split kind keep one (register budget)
-  static const int qs2 = getenv("FDM_ATTN_QS2") ? atoi(getenv("FDM_ATTN_QS2")) : 384;
+  constexpr int qs2 = 384;
   const int groups = (a.B * a.H + 7) / 8 * 8;        // (clip, head) pairs padded to whole XCD rounds
   if constexpr (HD <= 128 && Opnd<T>::NP == 1) {
     if (a.L >= qs2) {

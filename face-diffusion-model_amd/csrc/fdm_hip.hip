@@ -135,7 +135,7 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if ((a->ln_colsum || a->rln_gamma) && !a->ln_stat_in) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding needs ln_stat_in");
   if (a->rln_gamma && (!a->rln_beta || !a->resid)) return fail(FDM_ERR_ARG, "gemm: rln_gamma needs rln_beta and resid");
   if ((a->stat_out || a->ln_stat_in) && (a->batch > 1 || a->out_batch_stride)) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding is not batched");
-  if (a->tile < 0 || a->tile > FDM_TILE_MAX) return fail(FDM_ERR_ARG, "gemm: unknown tile %d", a->tile);
+  if (a->tile < 0 || (a->tile & ~FDM_TILE_GENERAL) > FDM_TILE_MAX) return fail(FDM_ERR_ARG, "gemm: unknown tile %d", a->tile);
   if (a->sched_fuse) {
     const fdm_sched_args& sc = a->sched;
     if (sc.mode != 0 && sc.mode != 1) return fail(FDM_ERR_ARG, "gemm: fused scheduler supports mode 0 (DDPM) and 1 (DDIM)");

@@ -788,6 +788,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const fdm_gemm_args p) {
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (FDM_PP_PRIO == 2) __builtin_amdgcn_s_setprio(0);
     PP_STAMP(1);
+    // this wave's fragment reads of tile kt have RETURNED before the barrier: the other group's next LOAD slot issues LDS-DMA
+    // into the stage a wave of this group may still be reading otherwise (the stage-reuse argument above counts a read as done
+    // once it is issued; the first MFMA of COMPUTE waits for the same counter anyway)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // ---- COMPUTE(kt)
     PP_STAMP(2);
@@ -895,7 +899,7 @@ static bool gemm_all_tiles_lean(const fdm_gemm_args& a) {
 }
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
 static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
-  static const bool no_lean = getenv("FDM_GEMM_LEAN") && !strcmp(getenv("FDM_GEMM_LEAN"), "0");
+  const bool no_lean = (a.tile & FDM_TILE_GENERAL) != 0;      // tests: the edge-handling kernel on a shape that does not need it
   if (gemm_act_is_heavy(a.act)) {
     if (!no_lean && !a.out_kp && !a.out_vp && !a.stat_out && !a.ln_stat_in && gemm_all_tiles_lean<T, BM, BN>(a))
       return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_LEAN>(a, s);
@@ -929,8 +933,8 @@ static hipError_t gemm_pp_launch_t(const fdm_gemm_args& a, hipStream_t s) {
 }
 
 // ---- tile choice -------------------------------------------------------------------------------------------------------
-// fdm_gemm_args.tile (the caller's plan-time choice), else the FDM_GEMM_TILE override (env, read once: the FDM_TILE_* value
-// forced for every GEMM, for A/B measurements), else the heuristic below: gemm_heuristic_tile names the FDM_TILE_* a launch
+// fdm_gemm_args.tile (the caller's plan-time choice; FDM_TILE_GENERAL may be or-ed in), else the FDM_GEMM_TILE override (env, read
+// once: the FDM_TILE_* value forced for every GEMM, for A/B measurements), else the heuristic below: gemm_heuristic_tile names the FDM_TILE_* a launch
 // with tile = 0 resolves to (also exported as fdm_gemm_heuristic_tile, so that the plan-time tuner does not time a candidate
 // against itself).  Every tile accumulates k in the same order: the choice changes speed, never results.
 static int gemm_tile_override() {
@@ -938,11 +942,6 @@ static int gemm_tile_override() {
   return v;
 }
 static bool gemm_one_round(long long tiles) { return tiles > 192 && tiles <= 256; }
-// FDM_GEMM_RULES=0: the round-2 heuristic only (tile count thresholds), for A/B measurements of the round-3 rules
-static bool gemm_rules_on() {
-  static const bool v = [] { const char* e = getenv("FDM_GEMM_RULES"); return !(e && e[0] == '0'); }();
-  return v;
-}
 // 80x128 tiles that fill the chip in exactly one round (225..256 workgroups, e.g. 800 rows x 3072 columns = 240): every CU
 // streams one (80 + 128)-row operand pair instead of two or three 64x64 ones (12.7 vs 14.6 us bf16, 22.2 vs 28.4 us f16x3
 // on that shape; profiles/README.md round 3)
@@ -961,18 +960,17 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
   if (!split) {
     // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;
     // below that the 64x64 tile's extra blocks beat its higher L2->LDS traffic.
-    static const long long thr128 = [] { const char* e = getenv("FDM_GEMM_T128"); return e ? atoll(e) : 512LL; }();
-    static const long long thr128x64 = [] { const char* e = getenv("FDM_GEMM_T128X64"); return e ? atoll(e) : 700LL; }();
+    constexpr long long thr128 = 512, thr128x64 = 700;
     const long long t256 = (long long)((a.M + 255) / 256) * ((a.N + 127) / 128) * batch;
     // thousands of rows: the ping-pong loop on the 256x128 tile (the tuner's pick for the N <= 2048 sites from 6400 rows and
     // for FFN1 from 3200; `profiles/r3_rows_sweep`, `r3_tile_sweep`; bf16 only, whole column tiles)
-    const bool pp_ok = gemm_rules_on() && elem_bytes == 2 && a.N % 128 == 0 && a.K >= 1024;
+    const bool pp_ok = elem_bytes == 2 && a.N % 128 == 0 && a.K >= 1024;
     if (pp_ok && a.M >= 6000 && a.N <= 2048 && t256 >= 150) return FDM_TILE_256x128_PP;
     if (t128 >= thr128) return FDM_TILE_128x128;
     if (gemm_one_round_80(a)) return FDM_TILE_80x128;
     // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two
     //  64 KB rings per CU -- stay on it: MEAD's d = 512 sites at 1200-1600 rows lost 3-5 % on larger tiles)
-    if (gemm_rules_on() && elem_bytes == 2 && a.M > 1024 && (t64 > 512 || a.K >= 1024)) {
+    if (elem_bytes == 2 && a.M > 1024 && (t64 > 512 || a.K >= 1024)) {
       // 1100..4000 rows (batched clips, long clips, CFG): what the plan-time tuner picks there (profiles/r3_tile_sweep/), as rules.
       // A grid that fills the chip in exactly ONE round wins; else 128x64 -- on the 4-stage ring while its grid is one round, on the
       // 3-stage ring (72 KB: two workgroups per CU, all of <= 512 tiles resident) beyond.
@@ -986,8 +984,7 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
   }
   if (t128 >= 512) return FDM_TILE_128x128;
   if (gemm_one_round_80(a)) return FDM_TILE_80x128;
-  if (!gemm_rules_on()) {
-  } else if (a.M > 1024) {            // the tuner's picks at 1100..4000 rows as rules (see above)
+  if (a.M > 1024) {            // the tuner's picks at 1100..4000 rows as rules (see above)
     if (gemm_one_round(t128)) return FDM_TILE_128x128;
     if (t128x64 > 128 && t128x64 <= 256) return FDM_TILE_128x64_S3;     // (144 KB ring: one per CU, so one round only)
   } else {
@@ -1011,22 +1008,24 @@ template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   if (a.sched_fuse) {     // (validated: interior tiles only -> the lean epilogue)
     // thousands of rows: the scheduler-fused latent decoder on the ping-pong tile when the plan's tuner picked it
-    const bool pp = a.tile == FDM_TILE_256x128_PP || (a.tile == 0 && gemm_tile_override() == 0 && gemm_sched_fuse_heuristic_pp(a, (int)sizeof(typename Opnd<T>::E)));
+    const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+    const bool pp = tile_id == FDM_TILE_256x128_PP || (tile_id == 0 && gemm_tile_override() == 0 && gemm_sched_fuse_heuristic_pp(a, (int)sizeof(typename Opnd<T>::E)));
     if (pp && !a.ln_stat_in && a.N % 128 == 0)
       return gemm_pp_launch_h<T, 256, 128, 4, 2, 3, false, true, GEMM_LEAN>(a, s);
     return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
                         : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
   }
-  const int want = a.tile > 0 ? a.tile : gemm_tile_override();
+  const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+  const int want = tile_id > 0 ? tile_id : gemm_tile_override();
   switch (want > 0 ? want : gemm_heuristic_tile(a, (int)sizeof(typename Opnd<T>::E), false)) {
     case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
+    case FDM_TILE_96x128:                                                          // (retired id: nearest member)
     case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);  // 8 waves, 64x32 per wave
-    case FDM_TILE_96x128: return gemm_glds_launch_t<T, 96, 128, 2, 2, 4>(a, s);    // 4 waves, 48x64 per wave
-    case FDM_TILE_256x128: return gemm_glds_launch_t<T, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 64x64 per wave, 146 KB LDS
     case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);   // 3-stage ring: 48 KB -> 3 workgroups per CU
     case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
     case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 32 KB -> 4 workgroups per CU
     case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);    // 4 waves, 16x32 per wave, 36 KB
+    case FDM_TILE_256x128: return gemm_glds_launch_t<T, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 64x64 per wave, 146 KB LDS
     case FDM_TILE_256x128_PP: return gemm_pp_launch_t<T, 256, 128, 4, 2, 3>(a, s);   // ping-pong loop, 64x64 per wave, 146 KB
     case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);      // 8 waves, 80x16 per wave: 800 rows x 3072 = 240 workgroups
     case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4>(a, s);      // 8 waves, 32x32 per wave
@@ -1044,7 +1043,8 @@ static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
   if constexpr (std::is_same<T, bf16x3_t>::value) {
     return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                          // comparison mode: one tile
   } else {
-    const int want = a.tile > 0 ? a.tile : gemm_tile_override();
+    const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+    const int want = tile_id > 0 ? tile_id : gemm_tile_override();
     switch (want > 0 ? want : gemm_heuristic_tile(a, 2, true)) {
       case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);  // 96 KB
       case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);  // 64 KB -> 2 workgroups per CU

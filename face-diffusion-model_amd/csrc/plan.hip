@@ -215,7 +215,6 @@ struct fdm_plan {
   float *h = nullptr, *h2 = nullptr, *x1 = nullptr, *x0 = nullptr, *x = nullptr, *x2 = nullptr, *stats = nullptr;
   Mat xt, ht, h2t, x2t, ctx, u;
   void *q = nullptr, *kp = nullptr, *vp = nullptr;
-  float* qkv32 = nullptr;                    // FDM_F16X3 at head_dim 256: fp32 Q | K | V rows of the QKV projection (attention runs in fp32)
   long long q_lo = 0, kv_lo = 0;             // FDM_F16X3: plane distances of q and of the packed K / V buffers
   size_t kv_bytes = 0;
   float *AF = nullptr, *t1 = nullptr, *sty = nullptr, *em = nullptr, *emu = nullptr, *zeros = nullptr, *E0 = nullptr;
@@ -234,6 +233,8 @@ struct fdm_plan {
   std::map<std::string, long long> steps_seen;
   std::map<std::string, std::vector<fdm_gemm_args>>* tune_rec = nullptr;
   int tune_enabled = 1;
+  int tune_failed = 0;                       // opt-in request-path tuning runs that failed (heuristic tiles kept)
+  int want_fuse_ln3 = 0;                     // fdm_plan_set "fuse_ln3": fold norm3 into the GEMMs around it at the next commit
   int tune_lazy = 0;                         // 1: fdm_sample_graph may tune in-call once a shape has run 2000 steps (opt-in)
   long long last_graph_launches = 0, launches_per_step = 0;
 };
@@ -396,12 +397,11 @@ int commit_impl(fdm_plan* P, void* stream) {
     g.out_f32 = P->TT[l];
     FCK(fdm_op_gemm(&g, stream));
   }
-  // Optional (FDM_FUSE_LN3=1; bf16 and f16x3): norm3 of layer l-1 folded into the QKV / out-proj GEMMs of layer l and into the
+  // Optional (fdm_plan_set "fuse_ln3"; bf16 and f16x3): norm3 of layer l-1 folded into the QKV / out-proj GEMMs of layer l and into the
   // latent decoder,   LN(x) W^T + b = rstd (x W'^T - mu colsum(W')) + (W beta + b),  W' = W o gamma   -- 8 launches fewer.
   // Off by default since the GEMM kernels were specialised: the plain GEMM + LayerNorm launch is now as fast or faster than
   // the three GEMMs that carry the fold (profiles/README.md, A/B of the final build).
-  const char* env = getenv("FDM_FUSE_LN3");
-  P->fuse_ln3 = (P->dtype == FDM_BF16 || P->dtype == FDM_F16X3) && env && !strcmp(env, "1");
+  P->fuse_ln3 = (P->dtype == FDM_BF16 || P->dtype == FDM_F16X3) && P->want_fuse_ln3;     // fdm_plan_set(p, "fuse_ln3", 1) before the commit
   if (P->fuse_ln3) {
     auto make_fold = [&](const std::string& wname, const std::string& bname, int N, int l_prev, Fold* f) -> int {
       const float *W = nullptr, *b = nullptr, *gam = nullptr, *bet = nullptr;
@@ -523,11 +523,6 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   FCK(dalloc(P, &P->q, R * d * ea, true));
   FCK(dalloc(P, &P->kp, (size_t)B * repc * Lpad * d * ea, true));
   FCK(dalloc(P, &P->vp, (size_t)B * repc * Lpad * d * ea, true));
-  // (round 2 ran head_dim 256 in FDM_F16X3 through fp32 Q | K | V rows + fdm_op_pack_kv + the fp32 attention kernel: qkv32; the
-  //  split attention kernel now streams K / V at that head_dim, FDM_ATTN_HD256_F32=1 brings the old path back for A/B runs)
-  P->qkv32 = nullptr;
-  if (P->dtype == FDM_F16X3 && P->hd == 256 && getenv("FDM_ATTN_HD256_F32") && !strcmp(getenv("FDM_ATTN_HD256_F32"), "1"))
-    FCK(dalloc_t(P, &P->qkv32, R * 3 * d, true));
   P->q_lo = (long long)(R * d);
   P->kv_lo = (long long)((size_t)B * repc * Lpad * d);
   P->kv_bytes = (size_t)B * repc * Lpad * d * ea;
@@ -584,23 +579,16 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
       g.bias = f->bias; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.ln_colsum = f->colsum;
     }
     // FDM_F16X3: split attention on plane pairs (head_dim 64 / 128 hold a key tile's fragments in registers, 256 -- BIWI --
-    // streams them at one wave per SIMD).  kv32 (FDM_ATTN_HD256_F32=1, round 2's path, kept for A/B): the projection writes
-    // fp32 rows, fdm_op_pack_kv lays K / V out for the fp32 attention kernel (one launch more per layer), whose output returns
-    // as a plane pair.  FDM_BF16X3 (comparison mode): fp32 attention.
-    const bool kv32 = P->qkv32 != nullptr;
-    const bool split_attn = P->dtype == FDM_F16X3 && !kv32;
-    if (kv32) { g.out_f32 = P->qkv32; g.ldo_f32 = 3 * d; }
-    else if (split && !split_attn) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
+    // streams them at one wave per SIMD).  FDM_BF16X3 (comparison mode): fp32 attention.
+    const bool split_attn = P->dtype == FDM_F16X3;
+    if (split && !split_attn) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
     else { g.out_t = P->q; g.ldo_t = d; g.out_t_lo_off = split_attn ? P->q_lo : 0; }
-    if (!kv32) {
-      g.kv_lo_off = split_attn ? P->kv_lo : 0;
-      g.out_kp = P->kp; g.kp_col0 = d; g.out_vp = P->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = P->Lpad; g.kv_hd = P->hd;
-    }
+    g.kv_lo_off = split_attn ? P->kv_lo : 0;
+    g.out_kp = P->kp; g.kp_col0 = d; g.out_vp = P->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = P->Lpad; g.kv_hd = P->hd;
     FCK(plan_gemm(P, f ? "qkv_ln" : "qkv", g, stream));
-    if (kv32) FCK(fdm_op_pack_kv(P->qkv32 + d, 3 * d, P->qkv32 + 2 * d, 3 * d, P->kp, P->vp, BB, m.n_head, L, P->Lpad, P->hd, FDM_F32, stream));
     fdm_attn_args at;
     memset(&at, 0, sizeof(at));
-    at.Q = kv32 ? (void*)P->qkv32 : P->q; at.ldq = kv32 ? 3 * d : d;
+    at.Q = P->q; at.ldq = d;
     at.Kp = P->kp; at.Vp = P->vp; at.Lpad = P->Lpad; at.O = P->ctx.p; at.ldo = d;
     at.B = BB; at.H = m.n_head; at.L = L; at.hd = P->hd; at.dtype = split_attn ? FDM_F16X3 : (split ? FDM_F32 : P->dtype);
     at.scale = 1.0f / std::sqrt((float)P->hd); at.causal = 1; at.slopes = P->slopes; at.period = m.period;
@@ -717,8 +705,7 @@ int get_program(fdm_plan* P, const ProgSpec& sp, void* stream, fdm_prog** out) {
   fdm_prog* prog = nullptr;
   FCK(fdm_prog_create(&prog));
   int rc = fdm_prog_begin(prog);
-  const char* fs = getenv("FDM_FUSE_SCHED");
-  const bool fuse_sched = !P->cfg && sp.kind != 0 && !(fs && !strcmp(fs, "0"));
+  const bool fuse_sched = !P->cfg && sp.kind != 0;
   for (int rep = 0; rc == FDM_OK && rep < sp.reps; ++rep) {
     fdm_sched_args sc;
     memset(&sc, 0, sizeof(sc));
@@ -909,6 +896,11 @@ int tune_tiles(fdm_plan* P, int force, void* stream) {
   return rc;
 }
 
+// opt-in tuning on a request path: a failure is remembered (fdm_plan_get "tune_failed"), never returned
+void tune_soft(fdm_plan* P, void* stream) {
+  if (tune_tiles(P, 0, stream) != FDM_OK) ++P->tune_failed;
+}
+
 int tune_tiles_impl(fdm_plan* P, void* stream) {
   const std::string key = shape_key(P);
   hipStream_t s = (hipStream_t)stream;
@@ -944,7 +936,7 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
     return FDM_OK;
   };
   std::vector<int> cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64, FDM_TILE_128x64_S3,
-                            FDM_TILE_128x128, FDM_TILE_96x128, FDM_TILE_80x128, FDM_TILE_64x128};
+                            FDM_TILE_128x128, FDM_TILE_80x128, FDM_TILE_64x128};
   if (is_split(P->dtype)) cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64_S3, FDM_TILE_128x128, FDM_TILE_80x128, FDM_TILE_64x128};
   else if (P->R >= 1024) { cands.push_back(FDM_TILE_256x128); cands.push_back(FDM_TILE_256x128_PP); }
   // Which of them are worth a stopwatch is decided by a wave-quantisation model first.  What bounds these GEMMs is the
@@ -963,7 +955,6 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
       case FDM_TILE_128x64: return {128, 64, sp ? 3 : 4};
       case FDM_TILE_128x64_S3: return {128, 64, 3};
       case FDM_TILE_128x128: return {128, 128, sp ? 2 : 3};
-      case FDM_TILE_96x128: return {96, 128, 4};
       case FDM_TILE_80x128: return {80, 128, sp ? 3 : 4};
       case FDM_TILE_64x128: return {64, 128, sp ? 3 : 4};
       case FDM_TILE_256x128:
@@ -994,7 +985,7 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
       if (!is_split(P->dtype)) return tile;
       switch (tile) {
         case FDM_TILE_128x64: return FDM_TILE_128x64_S3;
-        case FDM_TILE_96x128: case FDM_TILE_256x128: case FDM_TILE_256x128_PP: return FDM_TILE_128x128;
+        case FDM_TILE_256x128: case FDM_TILE_256x128_PP: return FDM_TILE_128x128;
         default: return tile;
       }
     };
@@ -1213,7 +1204,11 @@ int fdm_audio_prepare_conds(fdm_plan* P, const float* hub, int B0, int N, int fw
     apply_tile_override(want);             // FDM_TILE_OVERRIDE pins tiles with or without the tuner (heuristic tiles elsewhere)
   }
   P->tiles = want;                          // (programs are keyed by the tile set they were recorded with)
-  return tune_tiles(P, 0, stream);        // plan-time: only for a shape that has already served >= 2000 steps untuned
+  // A request path never tunes by itself: fdm_plan_tune does, when the caller schedules it (fdm_plan_get "needs_tune" says when a
+  // shape has served >= 2000 steps on heuristic tiles).  Opt-in (fdm_plan_set "tune_lazy"): tune here / inside fdm_sample_graph
+  // once that is the case -- and even then a tuner failure keeps the heuristic tiles instead of failing the request.
+  if (P->tune_lazy) tune_soft(P, stream);
+  return FDM_OK;
 }
 
 int fdm_denoise_step(fdm_plan* P, const float* x_t, int t, float cfg_scale, float* x0_hat, float* x0_uncond, void* stream) {
@@ -1276,7 +1271,7 @@ int fdm_sample_graph(fdm_plan* P, const fdm_sample_args* a, void* stream) {
     if (a->out != a->x_T) HIPCK(hipMemcpyAsync(a->out, a->x_T, nb, hipMemcpyDeviceToDevice, s));
     return FDM_OK;
   }
-  if (P->tune_lazy) FCK(tune_tiles(P, 0, stream));
+  if (P->tune_lazy) tune_soft(P, stream);
   P->steps_seen[shape_key(P)] += n_steps;
   FCK(load_x(P, a->x_T, stream));
   FCK(set_steps(P, ts.data(), n_steps, stream));
@@ -1289,8 +1284,7 @@ int fdm_sample_graph(fdm_plan* P, const fdm_sample_args* a, void* stream) {
       if (a->record) HIPCK(hipMemcpyAsync(a->record + (size_t)i * P->M * P->m.d, P->x, nb, hipMemcpyDeviceToDevice, s));
     }
   } else {
-    static const int env_k = [] { const char* e = getenv("FDM_GRAPH_STEPS"); return e ? atoi(e) : 0; }();
-    int K = a->graph_steps > 0 ? a->graph_steps : (env_k > 0 ? env_k : 10);
+    int K = a->graph_steps > 0 ? a->graph_steps : 10;
     if (K > n_steps) K = n_steps;
     int left = n_steps;
     if (K > 1) {
@@ -1325,6 +1319,8 @@ int fdm_plan_get(fdm_plan* P, const char* key, long long* out) {
   else if (k == "fuse_ln3") *out = P->fuse_ln3;
   else if (k == "rows") *out = P->R;
   else if (k == "tuned") *out = P->tile_cache.count(shape_key(P)) ? 1 : 0;
+  else if (k == "needs_tune") { const std::string sk = shape_key(P); *out = (!P->tile_cache.count(sk) && P->tune_enabled && P->steps_seen.count(sk) && P->steps_seen[sk] >= 2000) ? 1 : 0; }
+  else if (k == "tune_failed") *out = P->tune_failed;
   else if (k.rfind("tile.", 0) == 0) { auto it = P->tiles.find(k.substr(5)); *out = it == P->tiles.end() ? 0 : it->second; }
   else return fail(FDM_ERR_ARG, "plan_get: unknown key '%s'", key);
   return FDM_OK;
@@ -1335,6 +1331,10 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
   const std::string k(key);
   if (k == "tune") { P->tune_enabled = value != 0; return FDM_OK; }
   if (k == "tune_lazy") { P->tune_lazy = value != 0; return FDM_OK; }
+  if (k == "fuse_ln3") {      // takes effect at the next commit (the folded weights are commit-time tables)
+    if ((value != 0) != (P->want_fuse_ln3 != 0)) { P->want_fuse_ln3 = value != 0; P->committed = false; P->prepared = false; return drop_programs(P, nullptr); }
+    return FDM_OK;
+  }
   if (k == "untune") {      // forget the tuned tiles of every shape (tests)
     P->tile_cache.clear(); P->steps_seen.clear(); P->tiles.clear();
     return drop_programs(P, nullptr);

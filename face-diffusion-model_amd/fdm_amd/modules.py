@@ -545,12 +545,17 @@ class VQAutoEncoder(ParamTree):
         emo = None if one_hot is None else one_hot.reshape(-1, one_hot.shape[-1])
         return self.plan(x.device).encode(x, emo)
 
-    def quant(self, x, one_hot=None):
+    def quant(self, x, one_hot=None, stats=True):
         """-> (z_q [B, c, L*G], emb_loss, (perplexity, min_encodings [B*L*G, 256], indices [B*L*G, 1])): the reference's
-        whole tuple (models/vq_vae_vocaset.py:31-33 -> models/lib/quantizer.py:35-64, beta = 0.25), all of it on the device."""
+        whole tuple (models/vq_vae_vocaset.py:31-33 -> models/lib/quantizer.py:35-64, beta = 0.25), all of it on the device.
+        stats=False (what the sampling pipeline passes: it uses z_q only, as every sampler of the reference does) skips the
+        training-side outputs -- no [B*L*G, 256] one-hot, no statistics kernels: (z_q, None, (None, None, indices))."""
         if not x.is_cuda:
             raise FdmError("VQAutoEncoder.quant runs on the HIP path only")
         emo = None if one_hot is None else one_hot.reshape(-1, one_hot.shape[-1])
+        if not stats:
+            zq, idx = self.plan(x.device).quant(x, emo)
+            return zq, None, (None, None, idx)
         return self.plan(x.device).quant_full(x, emo, beta=0.25)
 
     def decode(self, quant):

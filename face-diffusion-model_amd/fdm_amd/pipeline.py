@@ -66,6 +66,14 @@ def build_models(preset="vocaset", feature_dim=None, device="cuda:0", stage1=Non
     return diffusion, ae
 
 
+def _clip_x_T(shape, S, seed):
+    """DDPM start of a condition-batched call: one x_T per CLIP from the seed, shared by its S conditions (None for S = 1: the
+    sampler draws it, as before)."""
+    if S <= 1:
+        return None
+    return torch.randn(shape, generator=torch.Generator(device="cpu").manual_seed(seed)).repeat_interleave(S, dim=0)
+
+
 @torch.no_grad()
 def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emotion_one_hot=None, steps=None,
             ddim_steps=None, seed=0, device="cuda:0"):
@@ -75,7 +83,10 @@ def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emoti
     sampling call -- the reference sampler's style loop (samples/sample_diffusion_vocaset.py:71-83) batched: the audio
     encoder and the audio tables run once per clip, the S conditions ride the same step program.  Returns [B*S, L, V3] in
     (clip, condition) order; every condition of a clip starts from the clip's x_T (what S sequential calls with the same
-    seed do), so the DDIM results are bit-identical to the sequential loop's."""
+    seed do), so the DDIM results (eta = 0: x_T is the only random input) are bit-identical to the sequential loop's.  On the
+    DDPM paths (S > 1) the conditions share the clip's x_T too, but the per-step noise is keyed by the ROW (clip * S + condition):
+    every condition draws its own stream, as the reference's S sequential calls do with a running generator -- equal in
+    distribution to the sequential loop, not bit for bit."""
     model = diffusion.denoise_fn.model if isinstance(diffusion.denoise_fn, ClassifierFreeSampleModel) else diffusion.denoise_fn
     p = model.preset
     audio = torch.as_tensor(audio, dtype=torch.float32, device=device)
@@ -100,16 +111,16 @@ def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emoti
             emotion_one_hot = emotion_one_hot.expand(rows, -1)
         if id_one_hot.shape[0] == 1 and rows > 1:
             id_one_hot = id_one_hot.expand(rows, -1)
-        latent = diffusion.sample(audio, shape, emotion_one_hot, id_one_hot, seed=seed)
-        quanted, _, _ = autoencoder.quant(latent, emotion_one_hot)
+        latent = diffusion.sample(audio, shape, emotion_one_hot, id_one_hot, seed=seed, x_T=_clip_x_T(shape, S, seed))
+        quanted, _, _ = autoencoder.quant(latent, emotion_one_hot, stats=False)
     else:
         if ddim_steps:
             g = torch.Generator(device="cpu").manual_seed(seed)
             x_T = torch.randn(shape, generator=g).repeat_interleave(S, dim=0)
             latent = diffusion.ddim_sample(audio, shape, id_one_hot, ddim_steps, x_T=x_T)
         else:
-            latent = diffusion.sample(audio, shape, id_one_hot, seed=seed)
-        quanted, _, _ = autoencoder.quant(latent)
+            latent = diffusion.sample(audio, shape, id_one_hot, seed=seed, x_T=_clip_x_T(shape, S, seed))
+        quanted, _, _ = autoencoder.quant(latent, stats=False)
     out = autoencoder.decode(quanted)
     if template is not None:
         tp = torch.as_tensor(template, dtype=torch.float32, device=device).reshape(-1, 1, out.shape[-1])
@@ -175,7 +186,7 @@ def animate_many(diffusion, autoencoder, audios, templates=None, id_one_hots=Non
                 lat = diffusion.sample(dummy, shape, ids, seed=seed, x_T=x_T, clip0=g0)
             for i, b in enumerate(grp):
                 lb = lat[i:i + 1, :Ls[b] * p.G].contiguous()
-                q = autoencoder.quant(lb, emos[i:i + 1])[0] if p.n_emo else autoencoder.quant(lb)[0]
+                q = autoencoder.quant(lb, emos[i:i + 1], stats=False)[0] if p.n_emo else autoencoder.quant(lb, stats=False)[0]
                 out = autoencoder.decode(q)
                 if templates is not None:
                     tp = templates[b] if isinstance(templates, (list, tuple)) else templates

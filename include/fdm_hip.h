@@ -158,7 +158,7 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_64x64 1
 #define FDM_TILE_128x64 2
 #define FDM_TILE_128x128 3
-#define FDM_TILE_96x128 4
+#define FDM_TILE_96x128 4      /* retired (round 4: never picked by the tuner on any shape): resolves to 128x128 */
 #define FDM_TILE_256x128 5
 #define FDM_TILE_64x64_S3 6   /* 64x64 with a 3-stage ring (three workgroups per CU) */
 #define FDM_TILE_128x64_S3 7  /* 128x64 with a 3-stage ring (two workgroups per CU) */
@@ -168,6 +168,9 @@ typedef struct fdm_gemm_args {
 #define FDM_TILE_80x128 11     /* 80x128: ten row tiles for 800 rows -> 240 workgroups at N = 3072 (the QKV projection of four 200-frame clips) */
 #define FDM_TILE_64x128 12     /* 64x128: 13 row tiles for 800 rows -> 208 workgroups at N = 2048 in one round (FFN1 in the split modes) */
 #define FDM_TILE_MAX 12
+/* or-ed into `tile`: run the general (edge-handling) kernel even where a specialised one would do -- the two must agree bit for
+ * bit (tests/test_ops_gpu.py); not a tuning knob */
+#define FDM_TILE_GENERAL 0x100
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 /* The FDM_TILE_* value a launch of *a with tile = 0 resolves to (the library heuristic on M, N, K, batch and the operand kind;
  * no device work, a->tile is ignored).  The plan-time tuner uses it to leave the heuristic's own tile out of its candidates. */

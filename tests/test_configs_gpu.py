@@ -22,8 +22,9 @@ from oracle import weights as W  # noqa: E402
 DEV = "cuda:0"
 TOL = 1e-4
 # bf16 (BASELINE configs name it; outside the 1e-4 contract by construction): stated bar = 2x the distance measured on MI355X
-# (round 4, printed by the tests below with -s) over the first steps of each chain -- at t = 999.. the update coefficients are tiny
-BF16_FIRST_STEPS_BAR = {"cfg2": 1e-2, "cfg3": 1e-2, "cfg4": 1e-2}
+# (round 4, printed by the tests below with -s: 9.2e-5 / 1.44e-4 / 2.56e-4) over the first steps of each chain -- at t = 999..
+# the update coefficients are tiny
+BF16_FIRST_STEPS_BAR = {"cfg2": 2e-4, "cfg3": 3e-4, "cfg4": 5.2e-4}
 
 
 def mad(a, b):

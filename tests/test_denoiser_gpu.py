@@ -206,42 +206,40 @@ def _biwi_oracle_clip(w, a_paired, t, x, style):
     return Fn.linear(h, w["latent_decoder.weight"], w["latent_decoder.bias"]).reshape(L * p["G"], p["c"])
 
 
-def test_bf16_folded_norm3_matches_unfolded(monkeypatch):
-    """bf16 step program with norm3 folded into the surrounding GEMMs vs the same program with the LN3 launches."""
+def test_bf16_folded_norm3_matches_unfolded():
+    """bf16 step program with norm3 folded into the surrounding GEMMs (fdm_plan_set "fuse_ln3": opt-in, takes effect at the next
+    commit) vs the same program with the LN3 launches."""
     L, t = 50, 777
     inp = W.synth_inputs("vocaset", 2, L, seed=31)
     w = W.make_fdm_weights("vocaset")
     outs = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("FDM_FUSE_LN3", flag)
-        plan = DenoiserPlan("vocaset", w, BF16, DEV)
-        assert plan.fuse_ln3 == (flag == "1")
+    plan = DenoiserPlan("vocaset", w, BF16, DEV)
+    assert plan.fuse_ln3 is False                                        # opt-in since the specialised GEMM kernels
+    for flag in (0, 1, 0):
+        plan.set("fuse_ln3", flag)
         plan.prepare(inp["hub"], inp["style"], L=L)
-        outs[flag] = plan.denoise(inp["x"].to(DEV), t).cpu()
+        assert plan.fuse_ln3 == bool(flag) and plan.get("launches_per_step") in (0, 58, 50)
+        outs.setdefault(flag, []).append(plan.denoise(inp["x"].to(DEV), t).cpu())
+    assert torch.equal(outs[0][0], outs[0][1])                            # switching back rebuilds the unfolded program exactly
     ref = FO.fdm_forward(w, "vocaset", inp["hub"], t, inp["x"], inp["style"], None, folded=True)
-    assert mad(outs["1"], ref) < TOLBF and mad(outs["0"], ref) < TOLBF
-    assert mad(outs["1"], outs["0"]) < TOLBF
-    monkeypatch.delenv("FDM_FUSE_LN3")
-    assert DenoiserPlan("vocaset", w, BF16, DEV).fuse_ln3 is False       # opt-in since the specialised GEMM kernels
+    assert mad(outs[1][0], ref) < TOLBF and mad(outs[0][0], ref) < TOLBF
+    assert mad(outs[1][0], outs[0][0]) < TOLBF
 
 
-def test_f16x3_folded_norm3_is_opt_in_and_stays_in_contract(monkeypatch):
-    """FDM_FUSE_LN3=1 folds norm3 into the surrounding GEMMs in the split-fp16 program too (the same algebra on plane pairs:
-    8 launches fewer -- off by default): still inside the 1e-4 contract of the reference goldens."""
+def test_f16x3_folded_norm3_is_opt_in_and_stays_in_contract():
+    """fdm_plan_set "fuse_ln3" folds norm3 into the surrounding GEMMs in the split-fp16 program too (the same algebra on plane
+    pairs: 8 launches fewer -- off by default): still inside the 1e-4 contract of the reference goldens."""
     L, t = 50, 777
     inp = W.synth_inputs("vocaset", 2, L, seed=31)
     w = W.make_fdm_weights("vocaset")
     ref = FO.fdm_forward(w, "vocaset", inp["hub"], t, inp["x"], inp["style"], None, folded=True)
-    outs = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("FDM_FUSE_LN3", flag)
+    for flag in (1, 0):
         plan = DenoiserPlan("vocaset", w, F16X3, DEV)
-        assert plan.fuse_ln3 == (flag == "1")
+        assert plan.fuse_ln3 is False
+        plan.set("fuse_ln3", flag)
         plan.prepare(inp["hub"], inp["style"], L=L)
-        outs[flag] = plan.denoise(inp["x"].to(DEV), t).cpu()
-        assert mad(outs[flag], ref) < TOL32
-    monkeypatch.delenv("FDM_FUSE_LN3")
-    assert DenoiserPlan("vocaset", w, F16X3, DEV).fuse_ln3 is False
+        assert plan.fuse_ln3 == bool(flag)
+        assert mad(plan.denoise(inp["x"].to(DEV), t).cpu(), ref) < TOL32
 
 
 def test_full_size_cfg2_chain_properties():
@@ -440,9 +438,10 @@ def test_weight_update_rebuilds_tables_without_growing():
 
 
 def test_tile_override_applies_at_prepare_and_tuning_is_plan_time(monkeypatch):
-    """ADVICE r2: FDM_TILE_OVERRIDE pins call sites at fdm_audio_prepare whether or not the tuner runs (a C caller that only
-    calls fdm_sample_graph gets the pinned tiles), and a sampling call never tunes by itself: tuning is fdm_plan_tune, or
-    fdm_audio_prepare for a shape that has already served 2000 steps (or opt-in: fdm_plan_set(p, "tune_lazy", 1))."""
+    """ADVICE r2 / r3: FDM_TILE_OVERRIDE pins call sites at fdm_audio_prepare whether or not the tuner runs (a C caller that only
+    calls fdm_sample_graph gets the pinned tiles), and a request path (fdm_audio_prepare, fdm_sample_graph) never tunes by itself:
+    tuning is fdm_plan_tune -- fdm_plan_get "needs_tune" says when a shape has served 2000 steps on heuristic tiles -- unless the
+    caller opted in (fdm_plan_set(p, "tune_lazy", 1))."""
     w = W.make_fdm_weights("vocaset_tiny")
     L = 24
     inp = W.synth_inputs("vocaset_tiny", 2, L, seed=6)
@@ -457,11 +456,15 @@ def test_tile_override_applies_at_prepare_and_tuning_is_plan_time(monkeypatch):
     plan2 = DenoiserPlan("vocaset_tiny", w, F32, DEV)
     plan2.prepare(inp["hub"], inp["style"], L=L)
     ts = list(range(999, -1, -1))
+    assert plan2.get("needs_tune") == 0
     for _ in range(3):                                  # 3000 steps at this shape: still untuned, sampling calls only count
         out = plan2.sample_ddpm(inp["x"].to(DEV), ts, seed=1)
         assert plan2.get("tuned") == 0
-    plan2.prepare(inp["hub"], inp["style"], L=L)       # plan time: the shape has served >= 2000 steps -> tuned here
-    assert plan2.get("tuned") == 1
+    assert plan2.get("needs_tune") == 1                 # ... and say so
+    plan2.prepare(inp["hub"], inp["style"], L=L)       # a per-request call: no tuning latency spike here either
+    assert plan2.get("tuned") == 0 and plan2.get("needs_tune") == 1
+    plan2.tune()                                        # the caller schedules it off the request path
+    assert plan2.get("tuned") == 1 and plan2.get("needs_tune") == 0 and plan2.get("tune_failed") == 0
     assert torch.equal(plan2.sample_ddpm(inp["x"].to(DEV), ts, seed=1), out)        # tiles change speed, never results
     assert torch.equal(plan2.sample_ddim(inp["x"].to(DEV), 20), ref)
     plan3 = DenoiserPlan("vocaset_tiny", w, F32, DEV)

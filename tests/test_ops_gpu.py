@@ -675,17 +675,18 @@ def test_gemm_fused_scheduler_equals_gemm_then_sched_step(dtype, mode):
 
 def test_specialised_and_general_gemm_kernels_agree_bitwise():
     """The GEMM dispatch picks kernels specialised by what a launch can need (lean / packed-KV / LayerNorm-fold epilogues) when
-    the host-side predicate says every tile is interior; FDM_GEMM_LEAN=0 forces the general kernels.  Same bits either way,
-    over plain / heavy / edge shapes, packed K / V with aligned and unaligned clip lengths, the fold's producer and consumers,
-    the fused scheduler -- in every operand kind (tools/kernel_variant_hash.py, one fresh process per setting)."""
+    the host-side predicate says every tile is interior; FDM_TILE_GENERAL or-ed into fdm_gemm_args.tile forces the general
+    kernels.  Same bits either way, over plain / heavy / edge shapes, packed K / V with aligned and unaligned clip lengths, the
+    fold's producer and consumers, the fused scheduler -- in every operand kind (tools/kernel_variant_hash.py, one fresh process
+    per setting)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hashes = []
-    for lean in ("1", "0"):
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_variant_hash.py")], cwd=root,
-                           env=dict(os.environ, FDM_GEMM_LEAN=lean), capture_output=True, text=True, timeout=900)
+    for general in ("0", "1"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_variant_hash.py"), general], cwd=root,
+                           capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         hashes.append([ln for ln in r.stdout.splitlines() if ln.startswith("variant hash")][0])
     assert hashes[0] == hashes[1]

@@ -4,9 +4,10 @@
       stage: hubert | wav2vec | vqdecode      mode: bf16 | f16x3 | f32
 Prints wall time per call (events around `reps` calls after a warm-up) and the algorithmic TFLOP/s of the transformer layers.
 Under `rocprofv3 --kernel-trace --stats` / `--pmc` (tools/profile_encoders.sh) every launch of the process belongs to the stage."""
+import os
 import sys
 import torch
-sys.path.insert(0, 'face-diffusion-model_amd')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'face-diffusion-model_amd'))
 from fdm_amd import synth
 from fdm_amd._lib import BF16, F16X3, F32
 from fdm_amd.hubert import HUBERT_LARGE, WAV2VEC2_BASE, HubertPlan, num_frames

@@ -1,6 +1,6 @@
 """One hash over the outputs of a fixed set of GEMM launches that exercise every specialised kernel variant (plain, heavy
 activation, packed K / V with aligned and unaligned clip lengths, LayerNorm-fold producer / consumer, fused scheduler, batched).
-Run under FDM_GEMM_LEAN=0 (general kernels everywhere) and with the default dispatch: the hashes must be equal
+Run with argument 1 (FDM_TILE_GENERAL or-ed into every tile: general kernels everywhere) and 0 (the default dispatch): the hashes must be equal
 (tests/test_ops_gpu.py::test_specialised_and_general_gemm_kernels_agree_bitwise)."""
 import hashlib
 import math
@@ -29,8 +29,9 @@ def out_t(M, N, dt):
 
 
 g = torch.Generator().manual_seed(5)
+GEN = 0x100 if (len(sys.argv) > 1 and sys.argv[1] == '1') else 0      # include/fdm_hip.h FDM_TILE_GENERAL
 for dt in (BF16, F32, F16X3):
-    for tile in (0, 2, 3, 8):
+    for tile in (0 | GEN, 2 | GEN, 3 | GEN, 8 | GEN):
         # plain / heavy, interior and edge shapes
         for (M, N, K, act) in ((800, 1024, 1024, ACT_NONE), (130, 2048, 512, ACT_RELU), (64, 1024, 1024, ACT_MISH), (77, 192, 256, ACT_RELU)):
             A, W = opnd(torch.randn(M, K, generator=g), dt), opnd(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
@@ -76,6 +77,6 @@ for dt in (BF16, F32, F16X3):
     tseq = torch.tensor([500], dtype=torch.int32, device=DEV)
     step = torch.zeros(2, dtype=torch.int32, device=DEV)
     sc = ops.sched_args(0, None, None, None, M * N, n_per_clip=M * N, tseq=tseq, step=step, c1=tab[0], c2=tab[1], sigma=tab[2], noise=noise)
-    ops.gemm(A, W, M, N, K, resid=x, out_f32=x, sched=sc)
+    ops.gemm(A, W, M, N, K, resid=x, out_f32=x, sched=sc, tile=GEN)
     add(x)
 print("variant hash", h.hexdigest())
