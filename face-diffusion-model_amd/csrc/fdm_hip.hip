@@ -290,9 +290,9 @@ int fdm_op_conv0(const float* wav, const float* w, const float* bias, float* out
 int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L, int d, float eps, int dtype, void* stream) {
   if (!x || (!y_f32 && !y_t) || B <= 0 || L <= 0 || d <= 0) return fail(FDM_ERR_ARG, "leaky_instnorm: bad argument");
   return submit([=](hipStream_t s) {
-    dim3 grid((d + 255) / 256, B);
-    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::leaky_instnorm_kernel<fdm::bf16>), grid, dim3(256), 0, s, x, y_f32, (fdm::bf16*)y_t, L, d, eps);
-    else hipLaunchKernelGGL((fdm::leaky_instnorm_kernel<float>), grid, dim3(256), 0, s, x, y_f32, (float*)y_t, L, d, eps);
+    dim3 grid((d + 63) / 64, B);
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::leaky_instnorm_kernel<fdm::bf16>), grid, dim3(1024), 0, s, x, y_f32, (fdm::bf16*)y_t, L, d, eps);
+    else hipLaunchKernelGGL((fdm::leaky_instnorm_kernel<float>), grid, dim3(1024), 0, s, x, y_f32, (float*)y_t, L, d, eps);
     return hipGetLastError();
   }, stream, "leaky_instnorm");
 }

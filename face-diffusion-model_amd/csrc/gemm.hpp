@@ -966,6 +966,9 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
     // for FFN1 from 3200; `profiles/r3_rows_sweep`, `r3_tile_sweep`; bf16 only, whole column tiles)
     const bool pp_ok = elem_bytes == 2 && a.N % 128 == 0 && a.K >= 1024;
     if (pp_ok && a.M >= 6000 && a.N <= 2048 && t256 >= 150) return FDM_TILE_256x128_PP;
+    // a wide projection whose 256x128 grid is exactly one round (HuBERT's FFN1 at 4 x 10 s: 1992 x 4096 = 8 x 32 tiles; 29.6 us
+    // against 33.3 on the 512 tiles of 128x128, profiles/r4_pmc_hubert)
+    if (elem_bytes == 2 && a.M > 1024 && t128 >= thr128 && gemm_one_round(t256)) return FDM_TILE_256x128;
     if (t128 >= thr128) return FDM_TILE_128x128;
     if (gemm_one_round_80(a)) return FDM_TILE_80x128;
     // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two

@@ -17,8 +17,8 @@ from fdm_amd import ops  # noqa: E402
 from fdm_amd._lib import DTYPE_NAMES, F32  # noqa: E402
 
 DEV = "cuda:0"
-TILES = {0: "auto", 1: "64x64", 2: "128x64", 3: "128x128", 4: "96x128", 5: "256x128", 6: "64x64_s3", 7: "128x64_s3", 8: "64x64_s2",
-         9: "32x64_s3"}
+TILES = {0: "auto", 1: "64x64", 2: "128x64", 3: "128x128", 5: "256x128", 6: "64x64_s3", 7: "128x64_s3", 8: "64x64_s2",
+         9: "32x64_s3", 10: "256x128_pp", 11: "80x128", 12: "64x128"}
 
 
 def timeit(fn, n_rec=8, reps=10):
@@ -43,10 +43,7 @@ def main():
     code = DTYPE_NAMES[kind]
     dims = [int(v) for v in sys.argv[2:]] or [6400, 1024, 2048]
     peak = 157.3 if kind == "f32" else 2500.0
-    extra = int(os.environ.get("FDM_TILE_EXTRA", "0"))
     tiles = dict(TILES)
-    for t in range(10, 10 + extra):
-        tiles[t] = f"tile{t}"
     torch.manual_seed(0)
     out = []
     for i in range(0, len(dims), 3):

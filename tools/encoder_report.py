@@ -21,7 +21,10 @@ tlog = open(os.path.join(d, "trace.log")).read() if os.path.exists(os.path.join(
 cnt = collections.Counter()
 dur = collections.Counter()
 for r in rows:
-    k = (short(r["Kernel_Name"]), r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", "")))
+    # (the counter CSVs carry the total grid / workgroup sizes, the trace one value per dimension)
+    gx = int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1))
+    wx = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 0))) * int(r.get("Workgroup_Size_Y", 1)) * int(r.get("Workgroup_Size_Z", 1))
+    k = (short(r["Kernel_Name"]), str(gx), str(wx))
     cnt[k] += 1
     dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 n_calls = int(os.environ.get("ENC_REPS", "10")) + 3
