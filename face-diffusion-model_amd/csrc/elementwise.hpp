@@ -258,6 +258,65 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, const floa
   }
 }
 
+// The same layer with its LayerNorm(512) + GELU(erf) applied before anything is stored (HuBERT-large, feat_extract_norm = 'layer':
+// transformers HubertLayerNormConvLayer): a workgroup holds the 512 channels of 16 frames in registers (2 channels x 16 frames per
+// thread), so the two-pass statistics of every frame are two block reductions for all 16 frames at once and only the operand
+// copy leaves the chip -- 128 MB instead of 250 MB written + 250 MB read + 128 MB written at 4 x 10 s (round 4: 88 + 99 us ->
+// one kernel).
+template <typename T>
+__global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* wav, const float* w, const float* bias, const float* gamma,
+                                                            const float* beta, T* out, int n, int T0, float eps) {
+  constexpr int TT = 16;
+  __shared__ float red[2][TT][4];
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * TT;
+  const float* wv = wav + (size_t)b * n;
+  const int oa = threadIdx.x, ob = threadIdx.x + 256, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float wa[10], wb[10];
+#pragma unroll
+  for (int k = 0; k < 10; ++k) { wa[k] = w[oa * 10 + k]; wb[k] = w[ob * 10 + k]; }
+  const float ba = bias ? bias[oa] : 0.f, bb = bias ? bias[ob] : 0.f;
+  float xa[TT], xb[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int t = min(t0 + tt, T0 - 1);
+    float a = 0.f, c = 0.f;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      const float x = wv[5 * t + k];
+      a = fmaf(wa[k], x, a);
+      c = fmaf(wb[k], x, c);
+    }
+    xa[tt] = a + ba; xb[tt] = c + bb;
+  }
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const float s = wave_sum(xa[tt] + xb[tt]);
+    if (lane == 0) red[0][tt][wave] = s;
+  }
+  __syncthreads();
+  float mean[TT];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    mean[tt] = ((red[0][tt][0] + red[0][tt][1]) + (red[0][tt][2] + red[0][tt][3])) * (1.f / 512.f);
+    xa[tt] -= mean[tt]; xb[tt] -= mean[tt];
+    const float q = wave_sum(xa[tt] * xa[tt] + xb[tt] * xb[tt]);
+    if (lane == 0) red[1][tt][wave] = q;
+  }
+  __syncthreads();
+  const float ga = gamma[oa], gb = gamma[ob], ea = beta[oa], eb = beta[ob];
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const int t = t0 + tt;
+    if (t >= T0) break;
+    const float var = ((red[1][tt][0] + red[1][tt][1]) + (red[1][tt][2] + red[1][tt][3])) * (1.f / 512.f);
+    const float rstd = 1.f / sqrtf(var + eps);
+    T* o = out + ((size_t)b * T0 + t) * 512;
+    o[oa] = from_f32<T>(act_apply(xa[tt] * rstd * ga + ea, ACT_GELU_ERF));
+    o[ob] = from_f32<T>(act_apply(xb[tt] * rstd * gb + eb, ACT_GELU_ERF));
+  }
+}
+
 // LeakyReLU(0.2) then InstanceNorm1d (biased variance, no affine) over L per (clip, channel).  Workgroup = 16 time-lanes x 64
 // channels (coalesced across channels): the time-lanes stride over l and combine through LDS in a fixed order; three passes
 // (mean, centred variance, normalise) as the reference's two-pass statistics.  (Round 4: the first form ran one thread per
@@ -326,6 +385,58 @@ __global__ __launch_bounds__(1024) void time_groupnorm_kernel(const float* x, co
   if (!ok) return;
   const float gm = gamma ? gamma[ch] : 1.f, bt = beta ? beta[ch] : 0.f;
   for (int t = tl; t < Tn; t += 16) {
+    const float v = act_apply((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
+    const size_t o = ((size_t)b * Tn + t) * C + ch;
+    if (y_f32) y_f32[o] = v;
+    if (y_t) y_t[o] = from_f32<T>(v);
+  }
+}
+
+// The same normalisation for long clips, in two launches over time CHUNKS (round 4): the single-launch form above has C / 64 = 8
+// workgroups per clip whatever the clip's length -- 2.13 ms of a 3.1 ms wav2vec2-base forward at 10 s of audio (32 k frames).
+//   time_stats_kernel        grid (C / 64, chunks, B): per (clip, chunk, channel) sum and sum of squares in fp64 (one pass is exact
+//                            enough in fp64: the variance is formed as q / T - mean^2 in double), time-lanes combined in a fixed order
+//   time_norm_apply_kernel   grid (C / 64, chunks, B): every workgroup folds the chunk partials of its 64 channels in chunk order
+//                            (so the statistics do not depend on which workgroup reads them), then normalises its own chunk
+__global__ __launch_bounds__(1024) void time_stats_kernel(const float* x, double* part, int Tn, int C, int chunk) {
+  __shared__ double rs[16][64], rq[16][64];
+  const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + cl, c = blockIdx.y, b = blockIdx.z, nch = gridDim.y;
+  const bool ok = ch < C;
+  const float* xp = x + (size_t)b * Tn * C + (ok ? ch : 0);
+  const int t1 = min(Tn, (c + 1) * chunk);
+  double s = 0.0, q = 0.0;
+  if (ok) for (int t = c * chunk + tl; t < t1; t += 16) { const double v = (double)xp[(size_t)t * C]; s += v; q += v * v; }
+  rs[tl][cl] = s; rq[tl][cl] = q;
+  __syncthreads();
+  if (tl == 0 && ok) {
+    double ss = 0.0, qq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ss += rs[i][cl]; qq += rq[i][cl]; }
+    double* o = part + (((size_t)b * nch + c) * C + ch) * 2;
+    o[0] = ss; o[1] = qq;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(1024) void time_norm_apply_kernel(const float* x, const double* part, const float* gamma, const float* beta,
+                                                               float* y_f32, T* y_t, int Tn, int C, int chunk, float eps, int act) {
+  __shared__ float st[64][2];
+  const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+  const int ch = blockIdx.x * 64 + cl, c = blockIdx.y, b = blockIdx.z, nch = gridDim.y;
+  const bool ok = ch < C;
+  if (tl == 0) {
+    double ss = 0.0, qq = 0.0;
+    if (ok) for (int i = 0; i < nch; ++i) { const double* o = part + (((size_t)b * nch + i) * C + ch) * 2; ss += o[0]; qq += o[1]; }
+    const double mean = ss / Tn, var = fmax(qq / Tn - mean * mean, 0.0);
+    st[cl][0] = (float)mean; st[cl][1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (!ok) return;
+  const float mean = st[cl][0], rstd = st[cl][1];
+  const float gm = gamma ? gamma[ch] : 1.f, bt = beta ? beta[ch] : 0.f;
+  const float* xp = x + (size_t)b * Tn * C + ch;
+  const int t1 = min(Tn, (c + 1) * chunk);
+  for (int t = c * chunk + tl; t < t1; t += 16) {
     const float v = act_apply((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
     const size_t o = ((size_t)b * Tn + t) * C + ch;
     if (y_f32) y_f32[o] = v;

@@ -360,10 +360,15 @@ int fdm_hubert_forward(fdm_audio_encoder* E, const float* wav, int B, int n, int
   const size_t es = esize(dt), esl = esize(dtl);
   const bool split = dtl == FDM_F16X3;
   // --- conv feature extractor (channels-last) ---
-  FCK(fdm_op_conv0(wav, E->conv0_w, E->conv_b[0], E->x32, B, n, T[0], stream));
   void* xt = E->xa;
-  if (E->conv_layer_norm) FCK(layernorm(E->x32, E->conv_g[0], E->conv_beta[0], B * T[0], CD, FDM_ACT_GELU_ERF, nullptr, xt, dt, stream));
-  else FCK(fdm_op_time_groupnorm(E->x32, E->conv_g[0], E->conv_beta[0], nullptr, xt, B, T[0], CD, 1e-5f, FDM_ACT_GELU_ERF, dt, stream));
+  if (E->conv_layer_norm) {        // conv 0 + LayerNorm + GELU in one kernel: only the operand copy is stored
+    FCK(fdm_op_conv0_ln_gelu(wav, E->conv0_w, E->conv_b[0], E->conv_g[0], E->conv_beta[0], xt, B, n, T[0], 1e-5f, dt, stream));
+  } else {                         // wav2vec2-base: GroupNorm over time needs the whole clip's conv output first
+    FCK(fdm_op_conv0(wav, E->conv0_w, E->conv_b[0], E->x32, B, n, T[0], stream));
+    // (chunk statistics go through y32: the conv stack's fp32 scratch, free until layer 1's GEMM writes it)
+    FCK(fdm_op_time_groupnorm(E->x32, E->conv_g[0], E->conv_beta[0], nullptr, xt, B, T[0], CD, 1e-5f, FDM_ACT_GELU_ERF, dt, E->y32,
+                              (long long)B * T[1] * CD * 4, stream));
+  }
   int Tin = T[0];
   for (int i = 1; i < 7; ++i) {
     const int k = CONV_K[i], sd = CONV_S[i], To = T[i];

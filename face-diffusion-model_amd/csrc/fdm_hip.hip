@@ -287,6 +287,18 @@ int fdm_op_conv0(const float* wav, const float* w, const float* bias, float* out
   }, stream, "conv0");
 }
 
+int fdm_op_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, void* out,
+                         int B, int n, int T0, float eps, int dtype, void* stream) {
+  if (!wav || !w || !gamma || !beta || !out || B <= 0 || n < 10 || T0 != (n - 10) / 5 + 1) return fail(FDM_ERR_SHAPE, "conv0_ln_gelu: bad shape (n=%d, T0=%d)", n, T0);
+  if (dtype != FDM_F32 && dtype != FDM_BF16) return fail(FDM_ERR_ARG, "conv0_ln_gelu: dtype %d (fp32 or bf16 output)", dtype);
+  return submit([=](hipStream_t s) {
+    const dim3 grid((T0 + 15) / 16, B);
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<fdm::bf16>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (fdm::bf16*)out, n, T0, eps);
+    else hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<float>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (float*)out, n, T0, eps);
+    return hipGetLastError();
+  }, stream, "conv0_ln_gelu");
+}
+
 int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L, int d, float eps, int dtype, void* stream) {
   if (!x || (!y_f32 && !y_t) || B <= 0 || L <= 0 || d <= 0) return fail(FDM_ERR_ARG, "leaky_instnorm: bad argument");
   return submit([=](hipStream_t s) {
@@ -298,8 +310,22 @@ int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L,
 }
 
 int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, int B, int T, int C,
-                          float eps, int act, int dtype, void* stream) {
+                          float eps, int act, int dtype, void* scratch, long long scratch_bytes, void* stream) {
   if (!x || (!y_f32 && !y_t) || B <= 0 || T <= 0 || C <= 0) return fail(FDM_ERR_ARG, "time_groupnorm: bad argument");
+  // long clips with a scratch buffer: statistics and normalisation over time chunks (two launches, hundreds of workgroups)
+  const int nch = T >= 4096 ? std::min(64, (T + 1023) / 1024) : 1;
+  const int chunk = ((T + nch - 1) / nch + 15) / 16 * 16;
+  const long long need = (long long)B * nch * C * 2 * (long long)sizeof(double);
+  if (scratch && nch > 1 && scratch_bytes >= need && ((uintptr_t)scratch % 8) == 0) {
+    double* part = (double*)scratch;
+    return submit([=](hipStream_t s) {
+      const dim3 grid((C + 63) / 64, nch, B);
+      hipLaunchKernelGGL(fdm::time_stats_kernel, grid, dim3(1024), 0, s, x, part, T, C, chunk);
+      if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::time_norm_apply_kernel<fdm::bf16>), grid, dim3(1024), 0, s, x, (const double*)part, gamma, beta, y_f32, (fdm::bf16*)y_t, T, C, chunk, eps, act);
+      else hipLaunchKernelGGL((fdm::time_norm_apply_kernel<float>), grid, dim3(1024), 0, s, x, (const double*)part, gamma, beta, y_f32, (float*)y_t, T, C, chunk, eps, act);
+      return hipGetLastError();
+    }, stream, "time_groupnorm");
+  }
   return submit([=](hipStream_t s) {
     dim3 grid((C + 63) / 64, B);
     if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::time_groupnorm_kernel<fdm::bf16>), grid, dim3(1024), 0, s, x, gamma, beta, y_f32, (fdm::bf16*)y_t, T, C, eps, act);

@@ -513,6 +513,15 @@ def test_small_ops():
     o = torch.zeros(2, T0, 512, device=DEV)
     ops.conv0(wav.to(DEV), w0.to(DEV), b0.to(DEV), o, 2, 4000, T0)
     assert rel(o, F.conv1d(wav.unsqueeze(1), w0, b0, stride=5).transpose(1, 2)) < 1e-5
+    # conv0 + LayerNorm(512) + GELU(erf) in one kernel (HuBERT-large's first conv layer), fp32 and bf16 outputs; T0 not a multiple of 16
+    gam, bet = torch.randn(512, generator=g), torch.randn(512, generator=g)
+    ref = F.gelu(F.layer_norm(F.conv1d(wav.unsqueeze(1), w0, b0, stride=5).transpose(1, 2), (512,), gam, bet, 1e-5))
+    o = torch.zeros(2, T0, 512, device=DEV)
+    ops.conv0_ln_gelu(wav.to(DEV), w0.to(DEV), b0.to(DEV), gam.to(DEV), bet.to(DEV), o, 2, 4000, T0)
+    assert T0 % 16 and rel(o, ref) < 1e-5
+    ob = torch.zeros(2, T0, 512, device=DEV, dtype=torch.bfloat16)
+    ops.conv0_ln_gelu(wav.to(DEV), w0.to(DEV), b0.to(DEV), gam.to(DEV), bet.to(DEV), ob, 2, 4000, T0)
+    assert torch.equal(ob, o.to(torch.bfloat16))
     # leaky + instance norm
     xi = torch.randn(2, 37, 1024, generator=g)
     o = torch.zeros(2, 37, 1024, device=DEV)
@@ -690,3 +699,26 @@ def test_specialised_and_general_gemm_kernels_agree_bitwise():
         assert r.returncode == 0, r.stdout + r.stderr
         hashes.append([ln for ln in r.stdout.splitlines() if ln.startswith("variant hash")][0])
     assert hashes[0] == hashes[1]
+
+
+def test_time_groupnorm_single_launch_and_chunked_forms():
+    """GroupNorm(num_groups = C) over time + GELU (wav2vec2-base's first conv layer): the single-launch form (short clips, or no
+    scratch) and the chunked two-launch form (>= 4096 frames with a scratch buffer: fp64 chunk statistics) against torch, fp32 and
+    bf16 outputs; T not a multiple of the chunk, C not a multiple of 64."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(11)
+    for (B, T, C) in ((2, 300, 512), (2, 9001, 512), (1, 5000, 96)):
+        x = torch.randn(B, T, C, generator=g) * 0.7 + 0.3
+        gam, bet = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        ref = F.gelu(F.group_norm(x.transpose(1, 2), C, gam, bet, 1e-5)).transpose(1, 2)
+        scratch = torch.zeros(B * 64 * C * 2, device=DEV, dtype=torch.float64)
+        outs = []
+        for sc in (None, scratch):
+            o = torch.zeros(B, T, C, device=DEV)
+            ops.time_groupnorm(x.to(DEV), gam.to(DEV), bet.to(DEV), B, T, C, y_f32=o, act=ACT_GELU_ERF, scratch=sc)
+            assert rel(o, ref) < 1e-5, (B, T, C, sc is not None)
+            outs.append(o)
+        ob = torch.zeros(B, T, C, device=DEV, dtype=torch.bfloat16)
+        ops.time_groupnorm(x.to(DEV), gam.to(DEV), bet.to(DEV), B, T, C, y_t=ob, act=ACT_GELU_ERF, dtype=ops.code_of(ob), scratch=scratch)
+        assert torch.equal(ob, outs[1].to(torch.bfloat16))
+    torch.cuda.synchronize()

@@ -72,8 +72,10 @@ for k, ns in sorted(dur.items(), key=lambda kv: -kv[1]):
     if nfe[k]:
         c = fe[k]
         fm = f"{c['FETCH_SIZE'] * 2 / 1024.0 / nfe[k]:.2f}"
-        if c["TCC_HIT_sum"] + c["TCC_MISS_sum"]:
-            hit = f"{100 * c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.0f} %"
+        miss = wr[k]["TCC_MISS_sum"] / nwr[k] if nwr[k] else 0.0
+        hits = c["TCC_HIT_sum"] / nfe[k]
+        if hits + miss:
+            hit = f"{100 * hits / (hits + miss):.0f} %"
     if nwr[k]:
         wm = f"{wr[k]['WRITE_SIZE'] / 1024.0 / nwr[k]:.2f}"
     print("| " + " | ".join(o + [mf, wt, hit, fm, wm]) + " |")

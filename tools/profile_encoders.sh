@@ -16,7 +16,7 @@ pass() { local name=$1; shift
   if [ -n "$f" ]; then cp $f $OUT/$name.raw.csv; else echo "pass $name: no counters"; tail -3 $OUT/$name.log; fi; rm -rf $OUT/raw; }
 STAGE_ARGS="$*"
 pass sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
-pass fetch FETCH_SIZE TCC_HIT_sum TCC_MISS_sum
+pass fetch FETCH_SIZE TCC_HIT_sum
 pass write WRITE_SIZE TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum
 python3 $ROOT/tools/encoder_report.py $OUT "$TAG: bench_encoders.py $*" > $OUT/summary.md
 rm -f $OUT/*.raw.csv $OUT/trace.csv
