@@ -3,7 +3,6 @@
 // All of these are bandwidth kernels: 16-byte accesses per lane, no re-reads, grid-stride where large.
 #pragma once
 #include "common.hpp"
-#include "layernorm.hpp"
 #include "sched.hpp"
 #include "../../include/fdm_hip.h"
 
@@ -20,7 +19,64 @@ namespace fdm {
 template <typename T, int NV, bool HEAVY>
 __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
   __shared__ float red[4][NV];
-  ln_row_body<T, NV, HEAVY>(p, blockIdx.x, threadIdx.x, red);
+  constexpr int d = 256 * NV;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = blockIdx.x, col = tid * 4;
+  const bool two = p.gamma2 != nullptr;
+  // every load of the kernel is requested before the first value is used: the row, the matrix addend and the affine vectors
+  // go out at once, the table row one dependent scalar load (the device-side step word) later -- one memory latency in
+  // all instead of one per operand (the kernel is launch-to-launch latency, not bandwidth)
+  const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 v = *(const f32x4*)(p.x + (size_t)row * d + col);
+  const bool has_e = p.add_mat || p.add_tab;
+  int arow = row;                      // (uniform: scalar arithmetic) conditions of a clip share the clip's addend rows
+  if (p.add_mat_group > 0) {
+    const int m = p.add_mat_wrap > 0 ? row % p.add_mat_wrap : row;
+    arow = (m / p.add_mat_group) * p.add_mat_L + m % p.add_mat_L;
+  }
+  const f32x4 em = p.add_mat ? *(const f32x4*)(p.add_mat + (size_t)arow * d + col) : zero;
+  const f32x4 g1 = *(const f32x4*)(p.gamma + col), b1 = *(const f32x4*)(p.beta + col);
+  const float *gp2 = two ? p.gamma2 : p.gamma, *bp2 = two ? p.beta2 : p.beta;      // (a select of pointers, not of loaded data)
+  const f32x4 g2 = *(const f32x4*)(gp2 + col), b2 = *(const f32x4*)(bp2 + col);
+  f32x4 et = zero;
+  if (p.add_tab) {
+    const int k = p.tab_step ? *p.tab_step : 0;
+    const int idx = p.tab_index ? p.tab_index[k] : k;
+    et = *(const f32x4*)(p.add_tab + (size_t)idx * d + col);
+  }
+  const f32x4 e = p.add_tab ? em + et : em;
+  auto block_sum = [&](float x, int slot) {
+    x = wave_sum(x);
+    if (lane == 0) red[slot][wave] = x;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NV; ++w) t += red[slot][w];
+    return t;
+  };
+  if (!two && has_e) v += e;
+  float mean = block_sum((v[0] + v[1]) + (v[2] + v[3]), 0) * (1.f / d);
+  v -= mean;
+  float var = block_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), 1) * (1.f / d);
+  float rstd = 1.f / sqrtf(var + p.eps);
+  if (two) {       // h = LN1(x); stage 2 input = h + add_mat + add_tab[idx]
+    v = v * rstd * g1 + b1;
+    if (has_e) v += e;
+    mean = block_sum((v[0] + v[1]) + (v[2] + v[3]), 2) * (1.f / d);
+    v -= mean;
+    var = block_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), 3) * (1.f / d);
+    rstd = 1.f / sqrtf(var + p.eps);
+  }
+  f32x4 y = v * rstd * g2 + b2;
+  if constexpr (HEAVY) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = act_apply(y[j], p.act);
+  } else if (p.act == ACT_RELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
+  }
+  if (p.y_f32) *(f32x4*)(p.y_f32 + (size_t)row * d + col) = y;
+  if (p.y_t) store_opnd4<T>((typename Opnd<T>::E*)p.y_t + (size_t)row * d + col, p.y_t_lo_off, y);
 }
 
 template <typename T, bool HEAVY>

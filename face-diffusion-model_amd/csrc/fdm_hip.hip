@@ -92,7 +92,6 @@ int fdm_abi_struct_size(const char* name) {
   if (n == "fdm_gemm_args") return (int)sizeof(fdm_gemm_args);
   if (n == "fdm_attn_args") return (int)sizeof(fdm_attn_args);
   if (n == "fdm_ln_args") return (int)sizeof(fdm_ln_args);
-  if (n == "fdm_tail_args") return (int)sizeof(fdm_tail_args);
   if (n == "fdm_model_desc") return (int)sizeof(fdm_model_desc);
   if (n == "fdm_sample_args") return (int)sizeof(fdm_sample_args);
   if (n == "fdm_vq_desc") return (int)sizeof(fdm_vq_desc);
@@ -151,38 +150,6 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   }
   fdm_gemm_args c = *a;
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
-}
-
-// a GEMM of the fused layer tail: what the lean 64x64 / 64x128 tile bodies cover, nothing else
-static bool tail_gemm_ok(const fdm_gemm_args& g, int rows, int dtype, int bn) {
-  const int bk = dtype == FDM_F32 ? 32 : 64;
-  return g.A && g.W && g.M == rows && g.dtype == dtype && g.N > 0 && g.N % bn == 0 && g.K > 0 && g.K % bk == 0 && g.batch <= 1 &&
-         (g.act == FDM_ACT_NONE || g.act == FDM_ACT_RELU) && !g.out_kp && !g.out_vp && !g.stat_out && !g.ln_stat_in && !g.sched_fuse &&
-         !g.resid_row_mod && !g.incr_counter && (g.out_f32 || g.out_t) && !g.out_batch_stride &&
-         (!g.out_f32 || (g.ldo_f32 % 4 == 0 && aligned16(g.out_f32))) && (!g.out_t || (g.ldo_t % 4 == 0 && aligned16(g.out_t))) &&
-         (!g.resid || (g.ldr % 4 == 0 && aligned16(g.resid))) && aligned16(g.A) && aligned16(g.W) && (!g.bias || aligned16(g.bias));
-}
-
-int fdm_op_layer_tail(const fdm_tail_args* a, void* stream) {
-  if (!a || !a->sync || !a->err) return fail(FDM_ERR_ARG, "layer_tail: null argument");
-  const int dt = a->out_proj.dtype, d = a->ln12.d;
-  if (dt != FDM_F32 && dt != FDM_BF16 && dt != FDM_F16X3) return fail(FDM_ERR_ARG, "layer_tail: dtype %d (fp32, bf16, f16x3)", dt);
-  if (a->rows < 64 || (d != 512 && d != 1024) || a->ln3.d != d || a->ln12.M != a->rows || a->ln3.M != a->rows)
-    return fail(FDM_ERR_SHAPE, "layer_tail: rows %d (>= 64), d %d (512 or 1024)", a->rows, d);
-  if (!tail_gemm_ok(a->out_proj, a->rows, dt, 64) || !tail_gemm_ok(a->ffn1, a->rows, dt, 128) || !tail_gemm_ok(a->ffn2, a->rows, dt, 64))
-    return fail(FDM_ERR_ARG, "layer_tail: the GEMMs must be plain ones (batch 1, bias / ReLU / residual only, aligned dense outputs, N %% 64 == 0, ffn1 N %% 128 == 0)");
-  for (const fdm_ln_args* l : {&a->ln12, &a->ln3}) {
-    if (!l->x || !l->gamma || !l->beta || (!l->y_f32 && !l->y_t) || l->dtype != dt || (l->act != FDM_ACT_NONE && l->act != FDM_ACT_RELU))
-      return fail(FDM_ERR_ARG, "layer_tail: bad LayerNorm arguments");
-  }
-  fdm_tail_args c = *a;
-  return submit([c](hipStream_t s) {
-    switch (c.out_proj.dtype) {
-      case FDM_BF16: return fdm::tail_launch_bf16(c, s);
-      case FDM_F16X3: return fdm::tail_launch_f16x3(c, s);
-      default: return fdm::tail_launch_f32(c, s);
-    }
-  }, stream, "layer_tail");
 }
 
 int fdm_gemm_heuristic_tile(const fdm_gemm_args* a) {

@@ -75,14 +75,12 @@ __device__ __forceinline__ void gemm_load_rowstats(const fdm_gemm_args& p, int m
 // cover them too.
 template <int MI, int NI> struct EpiPre { f32x4 csv[NI], bv[NI], gmv[NI], btv[NI], rv[MI][NI]; SchedCoef sc; };
 
-// COH (fused launches, csrc/tail.hpp): the residual tile was written earlier in the SAME launch by other CUs of this XCD, so it is
-// loaded past the CU's L1 (nt: served by the XCD's L2, which those stores have reached before the XCD-local barrier released us).
-template <typename T, int BM, int BN, int WM, int WN, bool SCHED = false, bool COH = false>
+template <typename T, int BM, int BN, int WM, int WN, bool SCHED = false>
 __device__ __forceinline__ void gemm_epi_preload(const fdm_gemm_args& p, int m0, int n0, int z, int wm, int wn, int g, int r16,
-                                                 bool ln_capable, EpiPre<BM / WM / 16, BN / WN / 16>& e, int Mlim = -1) {
+                                                 bool ln_capable, EpiPre<BM / WM / 16, BN / WN / 16>& e) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   if constexpr (SCHED) e.sc = sched_coef_load(p.sched);     // k -> t -> table entries: three dependent loads, hidden by the k loop
-  const int M = Mlim < 0 ? p.M : Mlim, N = p.N;     // Mlim: first row past the tile's row block (fused launches), else the matrix
+  const int M = p.M, N = p.N;
   const bool use_ln = ln_capable && p.ln_stat_in;
   const float* bias = p.bias ? p.bias + (size_t)z * p.bias_batch_stride : nullptr;
   const size_t ocol = (size_t)z * p.out_batch_stride;
@@ -101,8 +99,7 @@ __device__ __forceinline__ void gemm_epi_preload(const fdm_gemm_args& p, int m0,
     for (int mi = 0; mi < MI; ++mi) {
       const int m = m0 + wm * (BM / WM) + mi * 16 + r16;
       const size_t rrow = p.resid_row_mod > 0 ? (size_t)(min(m, M - 1) % p.resid_row_mod) : (size_t)min(m, M - 1);
-      if constexpr (COH) e.rv[mi][ni] = (p.resid && vec_r && full && m < M) ? __builtin_nontemporal_load((const f32x4*)(p.resid + ocol + rrow * p.ldr + n)) : zero;
-      else e.rv[mi][ni] = (p.resid && vec_r && full && m < M) ? *(const f32x4*)(p.resid + ocol + rrow * p.ldr + n) : zero;
+      e.rv[mi][ni] = (p.resid && vec_r && full && m < M) ? *(const f32x4*)(p.resid + ocol + rrow * p.ldr + n) : zero;
     }
   }
 }
@@ -138,8 +135,7 @@ constexpr int GEMM_LEAN = 1, GEMM_KV = 2, GEMM_FOLD = 4;
 template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true, bool SCHED = false, int SPEC = 0>
 __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               const EpiPre<BM / WM / 16, BN / WN / 16>& e, int m0, int n0, int z,
-                                              int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr,
-                                              int Mlim = -1) {
+                                              int wm, int wn, int g, int r16, float* rowstat = nullptr, char* tile_lds = nullptr) {
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
   constexpr bool LEAN = (SPEC & GEMM_LEAN) != 0;
   constexpr bool KVC = !LEAN || (SPEC & GEMM_KV), FOLDC = !LEAN || (SPEC & GEMM_FOLD);     // capabilities compiled in
@@ -147,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
   using KK = typename Opnd<T>::KV;    // operand kind of the packed K / V outputs (a plane pair for f16x3)
   using KV = typename Opnd<KK>::E;    // their element type
   constexpr int KNP = Opnd<KK>::NP;
-  const int M = Mlim < 0 ? p.M : Mlim, N = p.N;
+  const int M = p.M, N = p.N;
   // Whole-tile packed-V fast path: stage the tile transposed in LDS ([n][m], the ring is free after the k loop) and
   // store 16-byte runs of consecutive keys (one packed chunk each).  Needs the tile to lie entirely in the V columns
   // and clip boundaries on 16-byte multiples (L % (16 / sizeof(KV)) == 0); otherwise the per-element scatter is used.
@@ -378,7 +374,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
         float s = 0.f, q = 0.f;
 #pragma unroll
         for (int f = 0; f < 4; ++f) { s += comb[((size_t)(gq * 4 + f) * BM + t) * 2]; q += comb[((size_t)(gq * 4 + f) * BM + t) * 2 + 1]; }
-        float* so = p.stat_out + ((size_t)(n0 / 64 + gq) * p.M + (m0 + t)) * 2;
+        float* so = p.stat_out + ((size_t)(n0 / 64 + gq) * M + (m0 + t)) * 2;
         so[0] = s; so[1] = q;
       }
     }
@@ -399,13 +395,8 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// One output tile: rows [m0, min(m0 + BM, M)), columns [n0, n0 + BN) of batch z.  M = p.M for a plain launch; a fused launch
-// (csrc/tail.hpp) passes the end of the tile's row block: rows past it are neither stored nor, as clamped source rows, read.
-// COH: the A operand and the residual were written earlier in the same launch by CUs of this XCD -> A's LDS-DMA carries sc1 and
-// the residual loads nt (both past the CU's L1, served by the XCD's L2); W, bias and the other epilogue vectors are launch
-// constants and keep the default policy.
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0, bool COH = false>
-__device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int m0, const int n0, const int z, const int M, const bool first_wg) {
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
   using E = typename Opnd<T>::E;
   constexpr int NP = Opnd<T>::NP;                // operand planes (2 for the split kinds: hi, lo)
@@ -431,7 +422,7 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
 
   const int tid = threadIdx.x, lane = tid & 63;
-  if (p.incr_counter && tid == 0 && first_wg) {
+  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
     const int nv = *p.incr_counter + 1;
     *p.incr_counter = nv;
     if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
@@ -443,7 +434,9 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r16 = lane & 15;
-  const int N = p.N;
+  const int z = blockIdx.z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int M = p.M, N = p.N;
   const E* A = (const E*)p.A + (size_t)z * p.a_batch_stride;
   const E* W = (const E*)p.W + (size_t)z * p.w_batch_stride;
   const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);   // bytes hi plane -> lo plane
@@ -471,12 +464,11 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
     for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
       for (int i = 0; i < A_IPW; ++i) {
-        constexpr int AUX = COH ? 16 : 0;      // sc1
         if constexpr (UNEVEN) {
           if (i * NW + wave < NA)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (i * NW + wave) * 1024), 16, 0, AUX);
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (i * NW + wave) * 1024), 16, 0, 0);
         } else {
-          __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (wave * A_IPW + i) * 1024), 16, 0, AUX);
+          __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (wave * A_IPW + i) * 1024), 16, 0, 0);
         }
       }
 #pragma unroll
@@ -506,7 +498,7 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
     if (t < nk) issue(t);
   EpiPre<MI, NI> epre;
   constexpr bool FOLDC = !(SPEC & GEMM_LEAN) || (SPEC & GEMM_FOLD);
-  gemm_epi_preload<T, BM, BN, WM, WN, SCHED, COH>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre, M);
+  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
   if constexpr (FOLDC) gemm_load_rowstats<BM>(p, m0, rowstat);   // visible to every wave after the first barrier of the k loop
 
   // fragment (plane pl, k-step s) of tile row `row` in the stage at `base`: one ds_read_b128 through the XOR swizzle
@@ -591,19 +583,13 @@ __device__ __forceinline__ void gemm_glds_tile(const fdm_gemm_args& p, const int
 #ifdef FDM_GEMM_STAMPS
   if (stamps && tid == 0) stamps[2] = wall_clock64();
 #endif
-  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem, M);
+  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 #ifdef FDM_GEMM_STAMPS
   if (stamps && tid == 0) stamps[3] = wall_clock64();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (stamps && tid == 0) stamps[4] = wall_clock64();
 #endif
-}
-
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
-  gemm_glds_tile<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC>(p, blockIdx.y * BM, blockIdx.x * BN, blockIdx.z, p.M,
-                                                                 blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -10,9 +10,6 @@ hipError_t gemm_launch_f32(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_bf16(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_f16x3(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_bf16x3(const fdm_gemm_args& a, hipStream_t s);
-hipError_t tail_launch_f32(const fdm_tail_args& a, hipStream_t s);        // fused layer tail (tail.hpp), per operand kind
-hipError_t tail_launch_bf16(const fdm_tail_args& a, hipStream_t s);
-hipError_t tail_launch_f16x3(const fdm_tail_args& a, hipStream_t s);
 int gemm_heuristic_tile_of(const fdm_gemm_args& a);      // gemm_bf16.hip: the tile a launch with tile = 0 resolves to
 hipError_t attn_launch_f32(const fdm_attn_args& a, hipStream_t s);
 hipError_t attn_launch_bf16(const fdm_attn_args& a, hipStream_t s);

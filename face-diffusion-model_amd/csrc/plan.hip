@@ -234,8 +234,6 @@ struct fdm_plan {
   std::map<std::string, std::vector<fdm_gemm_args>>* tune_rec = nullptr;
   int tune_enabled = 1;
   int tune_failed = 0;                       // opt-in request-path tuning runs that failed (heuristic tiles kept)
-  int fuse_tail = 0;                         // fdm_plan_set "fuse_tail": out-proj .. norm3 of every layer as one launch (fdm_op_layer_tail)
-  unsigned int* tail_sync = nullptr;         // 16 x 32 ticket / barrier words + 1 error word of the fused launches (zeroed once)
   int want_fuse_ln3 = 0;                     // fdm_plan_set "fuse_ln3": fold norm3 into the GEMMs around it at the next commit
   int tune_lazy = 0;                         // 1: fdm_sample_graph may tune in-call once a shape has run 2000 steps (opt-in)
   long long last_graph_launches = 0, launches_per_step = 0;
@@ -546,12 +544,6 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
 // ---------------------------------------------------------------------------------------------------------------------
 // the step program: one denoiser pass, ws.x (+ its operand copy) -> ws.x0, or -> x_{t-1} when the scheduler update is fused
 // ---------------------------------------------------------------------------------------------------------------------
-// the fused layer tail covers the plain post-norm layer at d = 512 / 1024 in the fp32, bf16 and split-fp16 kinds
-bool tail_ok(const fdm_plan* P) {
-  return P->fuse_tail && !P->fuse_ln3 && P->tail_sync && (P->dtype == FDM_F32 || P->dtype == FDM_BF16 || P->dtype == FDM_F16X3) &&
-         (P->m.d == 512 || P->m.d == 1024) && P->m.ffn % 128 == 0 && P->R >= 64;
-}
-
 int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
   const fdm_model_desc& m = P->m;
   const int d = m.d, M = P->M, R = P->R, L = P->L;
@@ -606,15 +598,7 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
     FCK(need(P, lname(l, "self_attn.out_proj.bias"), d, &b));
     g = gemm_op(P, P->ctx, P->wt[lname(l, "self_attn.out_proj.weight")], R, d, d);
     g.bias = b; g.out_f32 = P->x1;
-    // fused tail (fdm_plan_set "fuse_tail"): the five row-local operators after the attention are recorded as ONE launch whose
-    // phases take exactly the arguments the operators would (csrc/tail.hpp); during a tuner recording the sites stay separate
-    const bool tail = tail_ok(P) && !P->tune_rec;
-    fdm_tail_args ta;
-    if (tail) { memset(&ta, 0, sizeof(ta)); ta.rows = R; ta.sync = P->tail_sync; ta.err = P->tail_sync + 16 * 32; }
-    if (tail) {
-      g.resid = P->h;
-      ta.out_proj = g;
-    } else if (!f) {
+    if (!f) {
       g.resid = P->h;
       FCK(plan_gemm(P, "out", g, stream));
     } else {
@@ -630,24 +614,15 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
     FCK(need(P, lname(l, "norm2.weight"), d, &ln.gamma2)); FCK(need(P, lname(l, "norm2.bias"), d, &ln.beta2));
     ln.y_f32 = P->h2; ln.dtype = P->dtype;
     if (both) { ln.y_t = P->h2t.p; ln.y_t_lo_off = P->h2t.lo; }
-    if (tail) ta.ln12 = ln; else FCK(fdm_op_layernorm(&ln, stream));
+    FCK(fdm_op_layernorm(&ln, stream));
     FCK(need(P, lname(l, "linear1.bias"), m.ffn, &b));
     g = gemm_op(P, P->h2t, P->wt[lname(l, "linear1.weight")], R, m.ffn, d);
     g.bias = b; g.act = FDM_ACT_RELU; set_out_t(g, P->u);
-    if (tail) ta.ffn1 = g; else FCK(plan_gemm(P, "ffn1", g, stream));
+    FCK(plan_gemm(P, "ffn1", g, stream));
     FCK(need(P, lname(l, "linear2.bias"), d, &b));
     g = gemm_op(P, P->u, P->wt[lname(l, "linear2.weight")], R, d, m.ffn);
     g.bias = b; g.resid = P->h2;
-    if (tail) {
-      g.out_f32 = P->x1;
-      ta.ffn2 = g;
-      memset(&ln, 0, sizeof(ln));
-      ln.x = P->x1; ln.M = R; ln.d = d; ln.eps = eps; ln.y_f32 = P->h; ln.dtype = P->dtype;
-      FCK(need(P, lname(l, "norm3.weight"), d, &ln.gamma)); FCK(need(P, lname(l, "norm3.bias"), d, &ln.beta));
-      if (both) { ln.y_t = P->ht.p; ln.y_t_lo_off = P->ht.lo; }
-      ta.ln3 = ln;
-      FCK(fdm_op_layer_tail(&ta, stream));
-    } else if (fuse) {      // x2 = h2 + FFN(h2): fp32 + operand copy + per-row partial sums for the folded norm3
+    if (fuse) {      // x2 = h2 + FFN(h2): fp32 + operand copy + per-row partial sums for the folded norm3
       g.out_f32 = P->x2; set_out_t(g, P->x2t); g.stat_out = P->stats;
       FCK(plan_gemm(P, "ffn2_stat", g, stream));
     } else {
@@ -1121,7 +1096,6 @@ int fdm_plan_destroy(fdm_plan* P) {
   for (void* p : P->ws_allocs) (void)hipFree(p);
   for (void* p : P->commit_allocs) (void)hipFree(p);
   for (void* p : P->allocs) (void)hipFree(p);
-  if (P->tail_sync) (void)hipFree(P->tail_sync);
   delete P;
   return FDM_OK;
 }
@@ -1343,12 +1317,6 @@ int fdm_plan_get(fdm_plan* P, const char* key, long long* out) {
   if (k == "launches_per_step") *out = P->launches_per_step;
   else if (k == "graph_launches") *out = P->last_graph_launches;
   else if (k == "fuse_ln3") *out = P->fuse_ln3;
-  else if (k == "fuse_tail") *out = tail_ok(P) ? 1 : 0;
-  else if (k == "tail_errors") {       // spin time-outs raised by fused launches so far (synchronises; non-zero: results undefined, fall back)
-    unsigned int e = 0;
-    if (P->tail_sync) { HIPCK(hipDeviceSynchronize()); HIPCK(hipMemcpy(&e, P->tail_sync + 16 * 32, sizeof(e), hipMemcpyDeviceToHost)); }
-    *out = e;
-  }
   else if (k == "rows") *out = P->R;
   else if (k == "tuned") *out = P->tile_cache.count(shape_key(P)) ? 1 : 0;
   else if (k == "needs_tune") { const std::string sk = shape_key(P); *out = (!P->tile_cache.count(sk) && P->tune_enabled && P->steps_seen.count(sk) && P->steps_seen[sk] >= 2000) ? 1 : 0; }
@@ -1363,15 +1331,6 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
   const std::string k(key);
   if (k == "tune") { P->tune_enabled = value != 0; return FDM_OK; }
   if (k == "tune_lazy") { P->tune_lazy = value != 0; return FDM_OK; }
-  if (k == "fuse_tail") {     // out-proj .. norm3 of every layer as one XCD-resident launch (csrc/tail.hpp); 0 = the five operators
-    if ((value != 0) == (P->fuse_tail != 0)) return FDM_OK;
-    if (value && !P->tail_sync) {
-      HIPCK(hipMalloc((void**)&P->tail_sync, (16 * 32 + 32) * sizeof(unsigned int)));
-      HIPCK(hipMemset(P->tail_sync, 0, (16 * 32 + 32) * sizeof(unsigned int)));
-    }
-    P->fuse_tail = value != 0;
-    return drop_programs(P, nullptr);
-  }
   if (k == "fuse_ln3") {      // takes effect at the next commit (the folded weights are commit-time tables)
     if ((value != 0) != (P->want_fuse_ln3 != 0)) { P->want_fuse_ln3 = value != 0; P->committed = false; P->prepared = false; return drop_programs(P, nullptr); }
     return FDM_OK;

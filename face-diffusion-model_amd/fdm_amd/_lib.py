@@ -69,13 +69,8 @@ class LnArgs(C.Structure):
                 ("add_mat_L", ci), ("add_mat_group", ci), ("add_mat_wrap", ci)]
 
 
-class TailArgs(C.Structure):
-    _fields_ = [("out_proj", GemmArgs), ("ffn1", GemmArgs), ("ffn2", GemmArgs), ("ln12", LnArgs), ("ln3", LnArgs),
-                ("rows", ci), ("sync", vp), ("err", vp), ("stamps", vp)]
-
-
 # public structs of include/fdm_hip.h -> their mirrors (sizes checked against the loaded library in lib())
-STRUCTS = {"fdm_sched_args": SchedArgs, "fdm_gemm_args": GemmArgs, "fdm_attn_args": AttnArgs, "fdm_ln_args": LnArgs, "fdm_tail_args": TailArgs,
+STRUCTS = {"fdm_sched_args": SchedArgs, "fdm_gemm_args": GemmArgs, "fdm_attn_args": AttnArgs, "fdm_ln_args": LnArgs,
            "fdm_model_desc": ModelDesc, "fdm_sample_args": SampleArgs, "fdm_vq_desc": VqDesc}
 
 # every symbol include/fdm_hip.h declares: name -> (restype, argtypes)
@@ -89,7 +84,6 @@ SYMBOLS = {
     "fdm_op_attention": (ci, [C.POINTER(AttnArgs), vp]),
     "fdm_op_pack_kv": (ci, [vp, ll, vp, ll, vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "fdm_op_layernorm": (ci, [C.POINTER(LnArgs), vp]),
-    "fdm_op_layer_tail": (ci, [C.POINTER(TailArgs), vp]),
     "fdm_op_sched_step": (ci, [C.POINTER(SchedArgs), vp]),
     "fdm_op_cast": (ci, [vp, vp, ll, ci, vp]),
     "fdm_op_vertex_err": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]),

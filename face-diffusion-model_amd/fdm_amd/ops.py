@@ -151,33 +151,6 @@ def layernorm(x, gamma, beta, M, d, *, add_mat=None, add_tab=None, tab_index=Non
     check(lib().fdm_op_layernorm(C.byref(a), stream()))
 
 
-def gemm_args(A, W, M, N, K, *, bias=None, act=ACT_NONE, resid=None, out_f32=None, out_t=None):
-    """A plain fdm_gemm_args (what layer_tail's phases take)."""
-    a = GemmArgs()
-    a.A, a.lda, a.W, a.ldw = _p(A), K, _p(W), K
-    a.M, a.N, a.K, a.batch, a.dtype = M, N, K, 1, code_of(A)
-    a.a_lo_off, a.w_lo_off, a.out_t_lo_off = _lo(A), _lo(W), _lo(out_t)
-    a.bias, a.act, a.resid, a.ldr = _p(bias), act, _p(resid), N
-    a.out_f32, a.ldo_f32, a.out_t, a.ldo_t = _p(out_f32), N, _p(out_t), N
-    return a
-
-
-def ln_args(x, gamma, beta, M, d, *, add_mat=None, y_f32=None, y_t=None, dtype=F32, gamma2=None, beta2=None, eps=1e-5):
-    a = LnArgs()
-    a.x, a.M, a.d, a.add_mat, a.gamma, a.beta, a.eps = _p(x), M, d, _p(add_mat), _p(gamma), _p(beta), eps
-    a.y_f32, a.y_t, a.dtype, a.gamma2, a.beta2, a.y_t_lo_off = _p(y_f32), _p(y_t), dtype, _p(gamma2), _p(beta2), _lo(y_t)
-    return a
-
-
-def layer_tail(out_proj, ln12, ffn1, ffn2, ln3, rows, sync, err, stamps=None):
-    """fdm_op_layer_tail: out-proj -> LN1+LN2 -> FFN1 -> FFN2 -> LN3 of a decoder layer as one XCD-resident launch."""
-    from ._lib import TailArgs
-    a = TailArgs()
-    a.out_proj, a.ffn1, a.ffn2, a.ln12, a.ln3 = out_proj, ffn1, ffn2, ln12, ln3
-    a.rows, a.sync, a.err, a.stamps = rows, _p(sync), _p(err), _p(stamps)
-    check(lib().fdm_op_layer_tail(C.byref(a), stream()))
-
-
 def sched_args(mode, x0, x, x_out, n, *, x0u=None, cfg_scale=0.0, n_per_clip=0, tseq=None, step=None, advance=0,
                c1=None, c2=None, sigma=None, sra=None, srm1=None, sqrt_an=None, c_n=None, noise=None, noise_stride=0,
                seed=0, clip0=0, x_out_t=None, arrive=None):

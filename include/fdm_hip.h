@@ -245,31 +245,6 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream);
 
 
 /* ------------------------------------------------------------------------------------------
- * The row-local tail of a post-norm decoder layer as ONE launch (round 4; models/fdm_vocaset.py:45-46,87 after the self-attention):
- *   out_proj (+bias, +residual) -> ln12 (norm1 + norm2 with the folded cross-attention addends) -> ffn1 (+bias, ReLU)
- *   -> ffn2 (+bias, +residual) -> ln3
- * given exactly as the five operators would be (the GEMMs' `tile` is ignored; outputs / inputs chained through the caller's buffers
- * as in the unfused sequence).  The rows are cut into 8 contiguous blocks, one per XCD of the MI355X; the phases of a block run on
- * the 32 CUs of its XCD and are separated by XCD-local barriers instead of kernel boundaries (csrc/tail.hpp).  Same arithmetic in
- * the same order as the five launches: bit-identical results.
- * Needs: the five operators' own preconditions; d = ln12.d in {512, 1024}; plain (lean) GEMMs -- batch 1, no packed K / V, no
- * LayerNorm folds, no scheduler fusion, N % 128 == 0 for ffn1 and N % 64 == 0 for the others, ReLU or no activation.
- * sync: 16 x 32 device words zeroed ONCE at allocation (tickets and barrier counters, never re-zeroed); err: one device word, zeroed
- * once, raised by a workgroup whose XCD did not receive its 32 workgroups within a bounded spin (results are then undefined and the
- * caller must fall back to the five operators and re-zero `sync`).  The launch must be the only work on the device while it runs
- * (256 workgroups of 512 threads, one per CU). */
-#define FDM_XCD 8
-typedef struct fdm_tail_args {
-  fdm_gemm_args out_proj, ffn1, ffn2;
-  fdm_ln_args ln12, ln3;
-  int rows;
-  unsigned int* sync;
-  unsigned int* err;
-  unsigned long long* stamps;     /* optional (profiling): [256][12] device words, 100 MHz clock at entry and after every phase / barrier of each workgroup */
-} fdm_tail_args;
-int fdm_op_layer_tail(const fdm_tail_args* a, void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Small elementwise / layout operators.                                                      */
 /* dst_t[i] = (dtype) src_f32[i]; split dtypes: hi plane at dst, lo plane at dst + n elements */
 int fdm_op_cast(const float* src, void* dst, long long n, int dtype, void* stream);

@@ -1,4 +1,6 @@
-"""A/B of the fused layer tail (fdm_plan_set "fuse_tail": out-proj .. norm3 of every layer as one XCD-resident launch, csrc/tail.hpp)
+"""[needs the library of commit 2451829: the fused layer tail was measured 9-20 % slower on every shape and removed again -- profiles/README.md,
+round 4, profiles/r4_fused_tail/]
+A/B of the fused layer tail (fdm_plan_set "fuse_tail": out-proj .. norm3 of every layer as one XCD-resident launch, csrc/tail.hpp)
 against the per-operator step program, on one box, alternating; also checks the two programs produce the same bits.
     python tools/bench_tail.py [shape ...]        shapes: cfg1 cfg2 cfg3 cfg4 cfg5rows mead249 voc8x498"""
 import os

@@ -1,4 +1,6 @@
-"""Per-phase clock stamps of the fused layer tail (fdm_tail_args.stamps): 8 layers' tails back to back as one hipGraph (distinct
+"""[needs the library of commit 2451829: the fused layer tail was measured 9-20 % slower on every shape and removed again -- profiles/README.md,
+round 4, profiles/r4_fused_tail/]
+Per-phase clock stamps of the fused layer tail (fdm_tail_args.stamps): 8 layers' tails back to back as one hipGraph (distinct
 weights), stamps of the LAST replay, averaged over the 256 workgroups; beside it the five operators as separate launches.
     python tools/tail_probe.py [bf16|f16x3] [rows]"""
 import math
