@@ -85,14 +85,48 @@ class _TensorKey:
 
 
 def _scalar_t(t):
-    """All clips of a call share the diffusion timestep (the reference runs B = 1); mixed timesteps would silently take
-    clip 0's, so they are rejected."""
+    """The timestep a step program runs at: all of its rows share it.  Callers route mixed per-clip timesteps through
+    _mixed_t / _rows_one_by_one first, so a mixed tensor here is a bug, not an input."""
     if not torch.is_tensor(t):
         return int(t)
     f = t.flatten()
     if f.numel() > 1 and bool((f != f[0]).any()):
-        raise FdmError("per-clip timesteps are not supported on this path: all clips of a call share t")
+        raise FdmError("internal: mixed timesteps reached a step program (they run one row block at a time)")
     return int(f[0])
+
+
+def _mixed_t(t):
+    """True for a [B] timestep tensor whose entries differ -- what the reference's signatures allow (t is a [B] tensor everywhere:
+    diffusion_BIWI_encoder_decoder.py:665,690,759) although its models only run B = 1."""
+    return torch.is_tensor(t) and t.numel() > 1 and bool((t.flatten() != t.flatten()[0]).any())
+
+
+def _row(x, i, rows):
+    """Row i of a per-row argument ([rows, ...] tensors; anything else is shared by all rows)."""
+    return x[i:i + 1] if (torch.is_tensor(x) and x.dim() > 1 and x.shape[0] == rows) else x
+
+
+def _rows_one_by_one(model, fn, t, rows, audio, *per_row):
+    """fn(audio_i, t_i, *args_i) for every row block i with its own timestep, results concatenated: per-clip timesteps mean what
+    they mean in the reference -- independent B = 1 calls (section 2 item 5 of DESIGN.md).  rows = B * S blocks over B clips."""
+    tf = t.flatten()
+    if tf.numel() != rows:
+        raise FdmError(f"{tf.numel()} timesteps for {rows} row blocks")
+    B = audio.shape[0] if torch.is_tensor(audio) else rows
+    S = max(rows // max(B, 1), 1)
+    inj = model._hub if getattr(model, "_hub_key", None) == "injected" else None
+    outs = []
+    try:
+        for i in range(rows):
+            b = i // S
+            if inj is not None:
+                model.set_audio_features(inj[b:b + 1])
+            a_i = audio[b:b + 1] if (torch.is_tensor(audio) and audio.dim() > 1) else audio
+            outs.append(fn(a_i, tf[i:i + 1], *[_row(x, i, rows) for x in per_row]))
+    finally:
+        if inj is not None:
+            model.set_audio_features(inj)
+    return torch.cat(outs)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -291,6 +325,10 @@ class _FDMBase(ParamTree):
     def _forward(self, audio, t, vertice, style, emo=None):
         if not vertice.is_cuda:
             raise FdmError("FDM.forward runs on the HIP path only: move inputs to the GPU")
+        if _mixed_t(t):      # one timestep per clip (the reference's [B] tensor): clips run one at a time, as its B = 1 calls do
+            st = style.reshape(-1, style.shape[-1]) if torch.is_tensor(style) else style
+            em = emo.reshape(-1, emo.shape[-1]) if torch.is_tensor(emo) else emo
+            return _rows_one_by_one(self, lambda a, ti, v, s_, e_: self._forward(a, ti, v, s_, e_), t, vertice.shape[0], audio, vertice, st, em)
         G = self.preset.G
         L = vertice.shape[1] // G
         hub = self.audio_features(audio)
@@ -358,6 +396,10 @@ class ClassifierFreeSampleModel(nn.Module):
 
     def forward(self, audio, t, x_noisy, emotion_one_hot, id_one_hot):
         m = self.model
+        if _mixed_t(t):
+            em = emotion_one_hot.reshape(-1, emotion_one_hot.shape[-1])
+            st = id_one_hot.reshape(-1, id_one_hot.shape[-1])
+            return _rows_one_by_one(m, lambda a, ti, x, e_, s_: self.forward(a, ti, x, e_, s_), t, x_noisy.shape[0], audio, x_noisy, em, st)
         L = x_noisy.shape[1] // m.preset.G
         plan = m.prepare(audio, L, id_one_hot, emotion_one_hot.reshape(-1, emotion_one_hot.shape[-1]), cfg=True)
         return plan.denoise(x_noisy.contiguous().float(), _scalar_t(t), cfg_scale=self.level)
@@ -403,6 +445,9 @@ class GaussianDiffusion(nn.Module):
         if not x_start.is_cuda:
             raise FdmError("GaussianDiffusion.q_sample runs on the HIP path only: move the latents to the GPU")
         noise = torch.randn_like(x_start) if noise is None else noise
+        if _mixed_t(t):      # per-clip timesteps (p_losses draws them: :759): the update is elementwise, one clip per launch
+            tf = t.flatten()
+            return torch.cat([self.q_sample(x_start[i:i + 1], tf[i:i + 1], noise[i:i + 1]) for i in range(x_start.shape[0])])
         from . import ops
         x0 = x_start.float().contiguous()
         z = noise.float().contiguous()
@@ -444,6 +489,12 @@ class GaussianDiffusion(nn.Module):
     @torch.no_grad()
     def p_sample(self, x, t, audio, *cond, clip_denoised=False, noise=None):
         """One reverse step on the HIP path (denoiser + fused scheduler update)."""
+        if _mixed_t(t):
+            model = self._split_cond(cond)[0]
+            z = noise if noise is not None else torch.randn_like(x)
+            rows = x.shape[0]
+            cr = [c.reshape(-1, c.shape[-1]) if torch.is_tensor(c) else c for c in cond]
+            return _rows_one_by_one(model, lambda a, ti, xi, zi, *ci: self.p_sample(xi, ti, a, *ci, noise=zi), t, rows, audio, x, z, *cr)
         plan, scale = self._plan(audio, x.shape, cond)
         tt = _scalar_t(t)
         z = noise if noise is not None else torch.randn_like(x)

@@ -103,3 +103,25 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     assert rec["parity"]["max_abs"] < 1e-4 and rec["parity"]["dtype"] == "f32"
     a, b = np.load(one), np.load(two)
     assert a.shape == b.shape == (2, 1600, 64) and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("config", ["shipped_biwi", "shipped_vocaset"])
+def test_bench_shipped_configs_print_a_complete_line(config):
+    """bench.py --config shipped_* (what the reference's samplers issue per test clip, end to end inside the timed call): one JSON
+    line with the contract's keys, the stage split, and -- for the VOCASET style loop -- the sequential B = 1 pipelines beside the
+    condition-batched call with bit-identical outputs."""
+    import json
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    r = subprocess.run([sys.executable, bench, "--config", config, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--headline-only",
+                        "--dtype", "f16x3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "roofline",
+              "stages_ms"):
+        assert k in d, k
+    st = d["stages_ms"]
+    assert set(st) >= {"audio_encoder", "tables", "quant", "decode", "sum"} and abs(st["sum"] - d["ms_per_step"]) / d["ms_per_step"] < 0.25
+    assert config in d["config"]["workload"] and d["value"] > 0 and 0 < d["roofline"]["frac"] < 1
+    if config == "shipped_vocaset":
+        assert d["sequential_loop"]["bit_identical_to_batched"] is True and d["speedup_vs_sequential_loop"] > 1.0

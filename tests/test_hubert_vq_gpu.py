@@ -341,6 +341,37 @@ def test_forward_loss_draws_one_timestep_per_clip():
     assert model._hub.shape[0] == B, "the injected features must be restored after the per-clip loop"
 
 
+def test_per_clip_timesteps_on_the_sampling_surface():
+    """The reference passes t as a [B] tensor everywhere (diffusion_BIWI_encoder_decoder.py:665,690,759); with different entries
+    per clip the drop-in runs the clips one at a time -- FDM.forward, q_sample and p_sample equal the independent B = 1 calls bit
+    for bit, and the injected audio features are restored afterwards."""
+    from fdm_amd.modules import FDM, GaussianDiffusion
+    model = FDM(feature_dim=1024, audio_encoder=False)
+    model.load_state_dict(W.make_fdm_weights("vocaset"), strict=False)
+    diff = GaussianDiffusion(model, timesteps=1000).to(DEV)
+    B, L = 3, 9
+    inp = W.synth_inputs("vocaset", B, L, seed=17)
+    hub, x, sty = inp["hub"].to(DEV), inp["x"].to(DEV), inp["style"].to(DEV)
+    audio = torch.zeros(B, 16, device=DEV)
+    t = torch.tensor([5, 700, 321], device=DEV)
+    z = torch.randn(x.shape, generator=torch.Generator().manual_seed(2)).to(DEV)
+    model.set_audio_features(hub)
+    out = model(audio, t, x, sty)
+    qs = diff.q_sample(x, t, z)
+    ps = diff.p_sample(x, t, audio, sty, noise=z)
+    assert model._hub.shape[0] == B
+    for i in range(B):
+        model.set_audio_features(hub[i:i + 1])
+        ti = t[i:i + 1]
+        assert torch.equal(out[i:i + 1], model(audio[i:i + 1], ti, x[i:i + 1], sty[i:i + 1])), i
+        assert torch.equal(qs[i:i + 1], diff.q_sample(x[i:i + 1], ti, z[i:i + 1])), i
+        assert torch.equal(ps[i:i + 1], diff.p_sample(x[i:i + 1], ti, audio[i:i + 1], sty[i:i + 1], noise=z[i:i + 1])), i
+    # equal entries still run as ONE step program
+    model.set_audio_features(hub)
+    same = model(audio, torch.full((B,), 44, device=DEV), x, sty)
+    assert same.shape == out.shape and torch.isfinite(same).all()
+
+
 def test_hubert_torch20_weight_norm_names_and_hf_prefixes():
     """A torch-2.0 / HF *ForCTC checkpoint spells the positional conv's weight-norm tensors weight_g / weight_v and prefixes
     every key with `hubert.`: both load and give the same features bit for bit."""
