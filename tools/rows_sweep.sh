@@ -12,5 +12,5 @@ for dt in bf16 f16x3; do
 done
 [ -n "$ROWS_SWEEP_NO_GEMM" ] && exit 0
 for dt in bf16 f16x3; do
-  FDM_TILE_EXTRA=1 FDM_GEMM_TILES_JSON=$O/gemm_tiles_$dt.json timeout 600 python tools/bench_gemm_tiles.py $dt 6400 1024 2048 6400 2048 1024 6400 3072 1024 6400 1024 1024 800 1024 1024 2>&1 | tee $O/gemm_tiles_$dt.txt
+  FDM_GEMM_TILES_JSON=$O/gemm_tiles_$dt.json timeout 600 python tools/bench_gemm_tiles.py $dt 6400 1024 2048 6400 2048 1024 6400 3072 1024 6400 1024 1024 800 1024 1024 2>&1 | tee $O/gemm_tiles_$dt.txt
 done
