@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, const floa
 // one kernel).
 template <typename T>
 __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* wav, const float* w, const float* bias, const float* gamma,
-                                                            const float* beta, T* out, int n, int T0, float eps) {
+                                                            const float* beta, typename Opnd<T>::E* out, long long lo_off, int n, int T0, float eps) {
   constexpr int TT = 16;
   __shared__ float red[2][TT][4];
   const int b = blockIdx.y;
@@ -311,9 +311,9 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* wav, co
     if (t >= T0) break;
     const float var = ((red[1][tt][0] + red[1][tt][1]) + (red[1][tt][2] + red[1][tt][3])) * (1.f / 512.f);
     const float rstd = 1.f / sqrtf(var + eps);
-    T* o = out + ((size_t)b * T0 + t) * 512;
-    o[oa] = from_f32<T>(act_apply(xa[tt] * rstd * ga + ea, ACT_GELU_ERF));
-    o[ob] = from_f32<T>(act_apply(xb[tt] * rstd * gb + eb, ACT_GELU_ERF));
+    typename Opnd<T>::E* o = out + ((size_t)b * T0 + t) * 512;
+    store_opnd1<T>(o + oa, lo_off, act_apply(xa[tt] * rstd * ga + ea, ACT_GELU_ERF));      // (split kind: hi plane here, lo plane lo_off elements on)
+    store_opnd1<T>(o + ob, lo_off, act_apply(xb[tt] * rstd * gb + eb, ACT_GELU_ERF));
   }
 }
 
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(1024) void leaky_instnorm_kernel(const float* x, fl
 // (biased variance), affine, then activation.  Workgroup = 16 time-lanes x 64 channels; the time-lanes
 // stride over t and combine through LDS; three passes (mean, centred variance, normalise).
 template <typename T>
-__global__ __launch_bounds__(1024) void time_groupnorm_kernel(const float* x, const float* gamma, const float* beta, float* y_f32, T* y_t,
-                                                              int Tn, int C, float eps, int act) {
+__global__ __launch_bounds__(1024) void time_groupnorm_kernel(const float* x, const float* gamma, const float* beta, float* y_f32,
+                                                              typename Opnd<T>::E* y_t, long long lo_off, int Tn, int C, float eps, int act) {
   __shared__ float red[16][64];
   const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
   const int ch = blockIdx.x * 64 + cl, b = blockIdx.y;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(1024) void time_groupnorm_kernel(const float* x, co
     const float v = act_apply((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
     const size_t o = ((size_t)b * Tn + t) * C + ch;
     if (y_f32) y_f32[o] = v;
-    if (y_t) y_t[o] = from_f32<T>(v);
+    if (y_t) store_opnd1<T>(y_t + o, lo_off, v);
   }
 }
 
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(1024) void time_stats_kernel(const float* x, double
 }
 template <typename T>
 __global__ __launch_bounds__(1024) void time_norm_apply_kernel(const float* x, const double* part, const float* gamma, const float* beta,
-                                                               float* y_f32, T* y_t, int Tn, int C, int chunk, float eps, int act) {
+                                                               float* y_f32, typename Opnd<T>::E* y_t, long long lo_off, int Tn, int C, int chunk, float eps, int act) {
   __shared__ float st[64][2];
   const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
   const int ch = blockIdx.x * 64 + cl, c = blockIdx.y, b = blockIdx.z, nch = gridDim.y;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(1024) void time_norm_apply_kernel(const float* x, c
     const float v = act_apply((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
     const size_t o = ((size_t)b * Tn + t) * C + ch;
     if (y_f32) y_f32[o] = v;
-    if (y_t) y_t[o] = from_f32<T>(v);
+    if (y_t) store_opnd1<T>(y_t + o, lo_off, v);
   }
 }
 

@@ -136,10 +136,12 @@ fdm_gemm_args gemm_args(int dtype, const void* A, const void* W, int M, int N, i
   a.ldr = N; a.ldo_f32 = N; a.ldo_t = N; a.ln_eps = 1e-5f;
   return a;
 }
+// (split dtype: y_t is a plane pair of M * d elements each, lo plane right behind the hi plane)
 int layernorm(const float* x, const float* gamma, const float* beta, int M, int d, int act, float* y32, void* yt, int dtype, void* stream) {
   fdm_ln_args a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.M = M; a.d = d; a.gamma = gamma; a.beta = beta; a.eps = 1e-5f; a.act = act; a.y_f32 = y32; a.y_t = yt; a.dtype = dtype;
+  if (yt && dtype == FDM_F16X3) a.y_t_lo_off = (long long)M * d;
   return fdm_op_layernorm(&a, stream);
 }
 int kv_pad(int L) { return (L + 31) / 32 * 32; }
@@ -161,9 +163,9 @@ const int CD = 512, POS_K = 128, POS_G = 16;
 // =====================================================================================================================
 struct fdm_audio_encoder {
   int kind = 0, n_layers = 0, dtype = FDM_F32;
-  // FDM_F16X3: the transformer layers (84 % of the FLOPs) run on split-fp16 operands, the front (conv stack, projection,
-  // positional conv) stays fp32 -- fp32-class features at well under half the fp32 encoder's time
-  int front_dtype() const { return dtype == FDM_F16X3 ? FDM_F32 : dtype; }
+  // FDM_F16X3: every GEMM of the encoder runs on split-fp16 operands -- the transformer layers (84 % of the FLOPs) since round 3,
+  // the front (conv stack, projection, positional conv: 26 % of the round-3 f16x3 forward on the fp32 matrix pipe) since round 4
+  int front_dtype() const { return dtype; }
   int D = 1024, H = 16, FFN = 4096;
   bool conv_layer_norm = true, conv_bias = true, stable_ln = true;
   Store st;
@@ -360,20 +362,24 @@ int fdm_hubert_forward(fdm_audio_encoder* E, const float* wav, int B, int n, int
   const size_t es = esize(dt), esl = esize(dtl);
   const bool split = dtl == FDM_F16X3;
   // --- conv feature extractor (channels-last) ---
+  // split front (FDM_F16X3): every activation matrix [rows, C] is a plane pair, lo plane rows * C elements behind the hi plane
+  const bool fsplit = dt == FDM_F16X3;
+  auto lo_of = [&](long long rows, long long cols) { return fsplit ? rows * cols : 0LL; };
   void* xt = E->xa;
   if (E->conv_layer_norm) {        // conv 0 + LayerNorm + GELU in one kernel: only the operand copy is stored
-    FCK(fdm_op_conv0_ln_gelu(wav, E->conv0_w, E->conv_b[0], E->conv_g[0], E->conv_beta[0], xt, B, n, T[0], 1e-5f, dt, stream));
+    FCK(fdm_op_conv0_ln_gelu(wav, E->conv0_w, E->conv_b[0], E->conv_g[0], E->conv_beta[0], xt, lo_of((long long)B * T[0], CD), B, n, T[0], 1e-5f, dt, stream));
   } else {                         // wav2vec2-base: GroupNorm over time needs the whole clip's conv output first
     FCK(fdm_op_conv0(wav, E->conv0_w, E->conv_b[0], E->x32, B, n, T[0], stream));
     // (chunk statistics go through y32: the conv stack's fp32 scratch, free until layer 1's GEMM writes it)
-    FCK(fdm_op_time_groupnorm(E->x32, E->conv_g[0], E->conv_beta[0], nullptr, xt, B, T[0], CD, 1e-5f, FDM_ACT_GELU_ERF, dt, E->y32,
-                              (long long)B * T[1] * CD * 4, stream));
+    FCK(fdm_op_time_groupnorm(E->x32, E->conv_g[0], E->conv_beta[0], nullptr, xt, lo_of((long long)B * T[0], CD), B, T[0], CD, 1e-5f, FDM_ACT_GELU_ERF, dt,
+                              E->y32, (long long)B * T[1] * CD * 4, stream));
   }
   int Tin = T[0];
   for (int i = 1; i < 7; ++i) {
     const int k = CONV_K[i], sd = CONV_S[i], To = T[i];
     fdm_gemm_args g = gemm_args(dt, xt, E->conv_w[i].p, To, CD, k * CD);
     g.lda = (long long)sd * CD; g.bias = E->conv_b[i]; g.batch = B; g.a_batch_stride = (long long)Tin * CD; g.out_batch_stride = (long long)To * CD;
+    g.a_lo_off = lo_of((long long)B * Tin, CD); g.w_lo_off = E->conv_w[i].lo;
     void* nx = (xt == E->xa) ? E->xb : E->xa;
     if (E->conv_layer_norm) {
       g.out_f32 = E->y32;
@@ -382,7 +388,7 @@ int fdm_hubert_forward(fdm_audio_encoder* E, const float* wav, int B, int n, int
       else FCK(layernorm(E->y32, E->conv_g[i], E->conv_beta[i], B * To, CD, FDM_ACT_GELU_ERF, E->g6, nullptr, dt, stream));
     } else {        // conv (no norm) + GELU fused in the GEMM epilogue
       g.act = FDM_ACT_GELU_ERF;
-      if (i < 6) g.out_t = nx; else g.out_f32 = E->g6;
+      if (i < 6) { g.out_t = nx; g.out_t_lo_off = lo_of((long long)B * To, CD); } else g.out_f32 = E->g6;
       FCK(fdm_op_gemm(&g, stream));
     }
     xt = nx; Tin = To;
@@ -394,15 +400,20 @@ int fdm_hubert_forward(fdm_audio_encoder* E, const float* wav, int B, int n, int
   const int M = B * N;
   fdm_gemm_args g = gemm_args(dt, E->ft, E->fp_w.p, N, D, CD);
   g.bias = E->fp_b; g.out_f32 = E->h; g.batch = B; g.a_batch_stride = (long long)T6 * CD; g.out_batch_stride = (long long)N * D;
-  void* ht = dt == FDM_BF16 ? E->ht : (void*)E->h;
-  if (dt == FDM_BF16) g.out_t = E->ht;
+  g.a_lo_off = lo_of((long long)B * T6, CD); g.w_lo_off = E->fp_w.lo;
+  void* ht = dt != FDM_F32 ? E->ht : (void*)E->h;
+  if (dt != FDM_F32) { g.out_t = E->ht; g.out_t_lo_off = lo_of((long long)M, D); }
   FCK(fdm_op_gemm(&g, stream));
   // --- positional conv embedding: h += GELU(grouped conv(h)), k = 128, groups = 16, pad 64, last output dropped ---
   const int dg = D / POS_G;
+  const long long xg_plane = (long long)POS_G * B * (N + POS_K) * dg;      // elements of one [groups, B, N + K, dg] plane
+  const size_t ee = fsplit ? 2 : es;                                     // bytes per element of a plane
   FCK(fdm_op_group_pad(ht, E->xg, B, N, D, POS_G, POS_K / 2, dt, stream));
+  if (fsplit) FCK(fdm_op_group_pad((const char*)ht + (size_t)M * D * 2, (char*)E->xg + (size_t)xg_plane * 2, B, N, D, POS_G, POS_K / 2, dt, stream));
   for (int b = 0; b < B; ++b) {
-    fdm_gemm_args pg = gemm_args(dt, (const char*)E->xg + (size_t)b * (N + POS_K) * dg * es, E->pc_w.p, N, dg, POS_K * dg);
+    fdm_gemm_args pg = gemm_args(dt, (const char*)E->xg + (size_t)b * (N + POS_K) * dg * ee, E->pc_w.p, N, dg, POS_K * dg);
     pg.lda = dg; pg.batch = POS_G; pg.a_batch_stride = (long long)B * (N + POS_K) * dg; pg.w_batch_stride = (long long)dg * POS_K * dg;
+    pg.a_lo_off = fsplit ? xg_plane : 0; pg.w_lo_off = E->pc_w.lo;
     pg.bias = E->pc_b; pg.bias_batch_stride = dg; pg.act = FDM_ACT_GELU_ERF;
     pg.resid = E->h + (size_t)b * N * D; pg.ldr = D; pg.out_f32 = E->h2 + (size_t)b * N * D; pg.ldo_f32 = D; pg.out_batch_stride = dg;
     FCK(fdm_op_gemm(&pg, stream));

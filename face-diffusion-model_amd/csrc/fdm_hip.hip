@@ -273,7 +273,8 @@ int fdm_op_group_pad(const void* in, void* out, int B, int T, int d, int groups,
   if (!in || !out || B <= 0 || T <= 0 || d <= 0 || groups <= 0 || d % groups || pad < 0) return fail(FDM_ERR_ARG, "group_pad: bad argument");
   const long long n = (long long)B * (T + 2 * pad) * d;
   return submit([=](hipStream_t s) {
-    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::group_pad_kernel<fdm::bf16>), dim3(grid_for(n)), dim3(256), 0, s, (const fdm::bf16*)in, (fdm::bf16*)out, B, T, d, groups, pad);
+    if (dtype == FDM_BF16 || dtype == FDM_F16X3)      // (one plane of a split operand moves like any 2-byte matrix: the caller passes each plane)
+      hipLaunchKernelGGL((fdm::group_pad_kernel<fdm::bf16>), dim3(grid_for(n)), dim3(256), 0, s, (const fdm::bf16*)in, (fdm::bf16*)out, B, T, d, groups, pad);
     else hipLaunchKernelGGL((fdm::group_pad_kernel<float>), dim3(grid_for(n)), dim3(256), 0, s, (const float*)in, (float*)out, B, T, d, groups, pad);
     return hipGetLastError();
   }, stream, "group_pad");
@@ -288,13 +289,15 @@ int fdm_op_conv0(const float* wav, const float* w, const float* bias, float* out
 }
 
 int fdm_op_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, void* out,
-                         int B, int n, int T0, float eps, int dtype, void* stream) {
+                         long long out_lo_off, int B, int n, int T0, float eps, int dtype, void* stream) {
   if (!wav || !w || !gamma || !beta || !out || B <= 0 || n < 10 || T0 != (n - 10) / 5 + 1) return fail(FDM_ERR_SHAPE, "conv0_ln_gelu: bad shape (n=%d, T0=%d)", n, T0);
-  if (dtype != FDM_F32 && dtype != FDM_BF16) return fail(FDM_ERR_ARG, "conv0_ln_gelu: dtype %d (fp32 or bf16 output)", dtype);
+  if (dtype != FDM_F32 && dtype != FDM_BF16 && dtype != FDM_F16X3) return fail(FDM_ERR_ARG, "conv0_ln_gelu: dtype %d (fp32, bf16 or FDM_F16X3 output)", dtype);
+  if (dtype == FDM_F16X3 && out_lo_off <= 0) return fail(FDM_ERR_ARG, "conv0_ln_gelu: split output needs out_lo_off");
   return submit([=](hipStream_t s) {
     const dim3 grid((T0 + 15) / 16, B);
-    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<fdm::bf16>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (fdm::bf16*)out, n, T0, eps);
-    else hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<float>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (float*)out, n, T0, eps);
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<fdm::bf16>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (fdm::bf16*)out, 0LL, n, T0, eps);
+    else if (dtype == FDM_F16X3) hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<fdm::f16x3_t>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (fdm::f16*)out, out_lo_off, n, T0, eps);
+    else hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<float>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (float*)out, 0LL, n, T0, eps);
     return hipGetLastError();
   }, stream, "conv0_ln_gelu");
 }
@@ -309,27 +312,31 @@ int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L,
   }, stream, "leaky_instnorm");
 }
 
-int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, int B, int T, int C,
+int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, long long y_t_lo_off, int B, int T, int C,
                           float eps, int act, int dtype, void* scratch, long long scratch_bytes, void* stream) {
   if (!x || (!y_f32 && !y_t) || B <= 0 || T <= 0 || C <= 0) return fail(FDM_ERR_ARG, "time_groupnorm: bad argument");
+  if (y_t && dtype == FDM_F16X3 && y_t_lo_off <= 0) return fail(FDM_ERR_ARG, "time_groupnorm: split y_t needs y_t_lo_off");
   // long clips with a scratch buffer: statistics and normalisation over time chunks (two launches, hundreds of workgroups)
   const int nch = T >= 4096 ? std::min(64, (T + 1023) / 1024) : 1;
   const int chunk = ((T + nch - 1) / nch + 15) / 16 * 16;
   const long long need = (long long)B * nch * C * 2 * (long long)sizeof(double);
+  const long long lo = y_t_lo_off;
   if (scratch && nch > 1 && scratch_bytes >= need && ((uintptr_t)scratch % 8) == 0) {
     double* part = (double*)scratch;
     return submit([=](hipStream_t s) {
       const dim3 grid((C + 63) / 64, nch, B);
       hipLaunchKernelGGL(fdm::time_stats_kernel, grid, dim3(1024), 0, s, x, part, T, C, chunk);
-      if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::time_norm_apply_kernel<fdm::bf16>), grid, dim3(1024), 0, s, x, (const double*)part, gamma, beta, y_f32, (fdm::bf16*)y_t, T, C, chunk, eps, act);
-      else hipLaunchKernelGGL((fdm::time_norm_apply_kernel<float>), grid, dim3(1024), 0, s, x, (const double*)part, gamma, beta, y_f32, (float*)y_t, T, C, chunk, eps, act);
+      if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::time_norm_apply_kernel<fdm::bf16>), grid, dim3(1024), 0, s, x, (const double*)part, gamma, beta, y_f32, (fdm::bf16*)y_t, 0LL, T, C, chunk, eps, act);
+      else if (dtype == FDM_F16X3) hipLaunchKernelGGL((fdm::time_norm_apply_kernel<fdm::f16x3_t>), grid, dim3(1024), 0, s, x, (const double*)part, gamma, beta, y_f32, (fdm::f16*)y_t, lo, T, C, chunk, eps, act);
+      else hipLaunchKernelGGL((fdm::time_norm_apply_kernel<float>), grid, dim3(1024), 0, s, x, (const double*)part, gamma, beta, y_f32, (float*)y_t, 0LL, T, C, chunk, eps, act);
       return hipGetLastError();
     }, stream, "time_groupnorm");
   }
   return submit([=](hipStream_t s) {
     dim3 grid((C + 63) / 64, B);
-    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::time_groupnorm_kernel<fdm::bf16>), grid, dim3(1024), 0, s, x, gamma, beta, y_f32, (fdm::bf16*)y_t, T, C, eps, act);
-    else hipLaunchKernelGGL((fdm::time_groupnorm_kernel<float>), grid, dim3(1024), 0, s, x, gamma, beta, y_f32, (float*)y_t, T, C, eps, act);
+    if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::time_groupnorm_kernel<fdm::bf16>), grid, dim3(1024), 0, s, x, gamma, beta, y_f32, (fdm::bf16*)y_t, 0LL, T, C, eps, act);
+    else if (dtype == FDM_F16X3) hipLaunchKernelGGL((fdm::time_groupnorm_kernel<fdm::f16x3_t>), grid, dim3(1024), 0, s, x, gamma, beta, y_f32, (fdm::f16*)y_t, lo, T, C, eps, act);
+    else hipLaunchKernelGGL((fdm::time_groupnorm_kernel<float>), grid, dim3(1024), 0, s, x, gamma, beta, y_f32, (float*)y_t, 0LL, T, C, eps, act);
     return hipGetLastError();
   }, stream, "time_groupnorm");
 }

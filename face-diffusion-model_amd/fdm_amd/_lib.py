@@ -95,11 +95,11 @@ SYMBOLS = {
     "fdm_op_pad_rows": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "fdm_op_group_pad": (ci, [vp, vp, ci, ci, ci, ci, ci, ci, vp]),
     "fdm_op_conv0": (ci, [vp, vp, vp, vp, ci, ci, ci, vp]),
-    "fdm_op_conv0_ln_gelu": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, vp]),
+    "fdm_op_conv0_ln_gelu": (ci, [vp, vp, vp, vp, vp, vp, ll, ci, ci, ci, cf, ci, vp]),
     "fdm_op_leaky_instnorm": (ci, [vp, vp, vp, ci, ci, ci, cf, ci, vp]),
     "fdm_op_adain": (ci, [vp, vp, vp, ci, ci, ci, cf, vp]),
     "fdm_op_mean_diff": (ci, [vp, vp, vp, vp, ll, ci, vp]),
-    "fdm_op_time_groupnorm": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, ci, ci, vp, ll, vp]),
+    "fdm_op_time_groupnorm": (ci, [vp, vp, vp, vp, vp, ll, ci, ci, ci, cf, ci, ci, vp, ll, vp]),
     "fdm_op_vq_quant": (ci, [vp, vp, vp, ci, ci, ci, ci, vp, vp, vp]),
     "fdm_op_vq_stats": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp]),
     "fdm_prog_create": (ci, [C.POINTER(vp)]),

@@ -213,7 +213,7 @@ def conv0(wav, w, bias, out, B, n, T0):
 
 def conv0_ln_gelu(wav, w, bias, gamma, beta, out, B, n, T0, eps=1e-5):
     """conv layer 0 + LayerNorm(512) + GELU(erf) of HuBERT-large in one kernel; out [B, T0, 512] fp32 or bf16."""
-    check(lib().fdm_op_conv0_ln_gelu(_p(wav), _p(w), _p(bias), _p(gamma), _p(beta), _p(out), B, n, T0, eps, code_of(out), stream()))
+    check(lib().fdm_op_conv0_ln_gelu(_p(wav), _p(w), _p(bias), _p(gamma), _p(beta), _p(out), _lo(out), B, n, T0, eps, code_of(out), stream()))
 
 
 def leaky_instnorm(x, B, L, d, *, y_f32=None, y_t=None, eps=1e-5, dtype=F32):
@@ -224,7 +224,7 @@ def time_groupnorm(x, gamma, beta, B, T, C, *, y_f32=None, y_t=None, eps=1e-5, a
     """scratch: an 8-byte aligned device buffer (>= B * min(64, ceil(T / 1024)) * C * 16 bytes) lets clips of >= 4096 frames run over
     time chunks (two launches, hundreds of workgroups) instead of C / 64 workgroups per clip."""
     nbytes = scratch.numel() * scratch.element_size() if scratch is not None else 0
-    check(lib().fdm_op_time_groupnorm(_p(x), _p(gamma), _p(beta), _p(y_f32), _p(y_t), B, T, C, eps, act, dtype, _p(scratch), nbytes, stream()))
+    check(lib().fdm_op_time_groupnorm(_p(x), _p(gamma), _p(beta), _p(y_f32), _p(y_t), _lo(y_t), B, T, C, eps, act, dtype, _p(scratch), nbytes, stream()))
 
 
 def mean_diff(a, b, l1=False):

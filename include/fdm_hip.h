@@ -265,7 +265,7 @@ int fdm_op_conv0(const float* wav, const float* w, const float* bias, float* out
 /* the same layer with the LayerNorm(512, eps) + GELU(erf) that follows it in HuBERT-large (feat_extract_norm = 'layer') applied
  * before the store: out [B, T0, 512] in fp32 or bf16 (dtype), nothing else written */
 int fdm_op_conv0_ln_gelu(const float* wav, const float* w, const float* bias, const float* gamma, const float* beta, void* out,
-                         int B, int n, int T0, float eps, int dtype, void* stream);
+                         long long out_lo_off, int B, int n, int T0, float eps, int dtype, void* stream);     /* dtype FDM_F16X3: a plane pair, lo plane out_lo_off elements on */
 /* per-(clip, channel) InstanceNorm1d over L after LeakyReLU(0.2): models/vq_vae_vocaset.py:204-209 */
 int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L, int d, float eps, int dtype, void* stream);
 /* GroupNorm(num_groups = C, affine) over time + activation, channels-last x [B, T, C]: first conv layer of
@@ -273,7 +273,7 @@ int fdm_op_leaky_instnorm(const float* x, float* y_f32, void* y_t, int B, int L,
 /* scratch (optional, 8-byte aligned, >= B * min(64, ceil(T / 1024)) * C * 16 bytes): with it, clips of T >= 4096 frames are
  * normalised over time chunks in two launches of hundreds of workgroups (fp64 chunk statistics folded in chunk order); without
  * it one launch of C / 64 workgroups per clip does the three passes (fine for short clips; the operator never allocates) */
-int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, int B, int T, int C,
+int fdm_op_time_groupnorm(const float* x, const float* gamma, const float* beta, float* y_f32, void* y_t, long long y_t_lo_off, int B, int T, int C,
                           float eps, int act, int dtype, void* scratch, long long scratch_bytes, void* stream);
 /* out[0] = mean(|a - b|^p), p = 2 (l1 = 0) or 1: the forward value of p_losses' F.mse_loss / F.l1_loss
  * (diffusion_BIWI_encoder_decoder.py:744-749); partial: >= 1024 floats of scratch; deterministic order */
