@@ -120,6 +120,22 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// GELU(erf) for the bf16 (throughput) kind: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside the 2^-9 rounding of the
+// bf16 value it feeds) on the hardware exp -- a dozen instructions instead of libm erff's ~50 per element (HuBERT's FFN1 epilogue,
+// the conv LayerNorm + GELU kernels).  The fp32 and split (parity) kinds keep erff.
+__device__ __forceinline__ float gelu_erf_fast(float v) {
+  const float x = fabsf(v) * 0.70710678118654752440f;
+  const float t = 1.f / (1.f + 0.3275911f * x);
+  const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+  const float e = 1.f - poly * __expf(-x * x);              // erf(|v| / sqrt 2)
+  return 0.5f * v * (1.f + (v < 0.f ? -e : e));
+}
+// activation in the arithmetic of operand kind T: the bf16 kind takes the fast GELU above, every other kind act_apply
+template <typename T> __device__ __forceinline__ float act_apply_t(float v, int act) {
+  if constexpr (std::is_same<T, bf16>::value) { if (act == ACT_GELU_ERF) return gelu_erf_fast(v); }
+  return act_apply(v, act);
+}
+
 // Reductions across the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48).  (gfx950's v_permlane16_swap /
 // v_permlane32_swap would do this in VALU, but neither the builtin nor inline asm gave the documented pair of results
 // in a probe on this toolchain, so these stay on the ds_bpermute path.)

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
   f32x4 y = v * rstd * g2 + b2;
   if constexpr (HEAVY) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) y[j] = act_apply(y[j], p.act);
+    for (int j = 0; j < 4; ++j) y[j] = act_apply_t<T>(y[j], p.act);
   } else if (p.act == ACT_RELU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
@@ -312,8 +312,8 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* wav, co
     const float var = ((red[1][tt][0] + red[1][tt][1]) + (red[1][tt][2] + red[1][tt][3])) * (1.f / 512.f);
     const float rstd = 1.f / sqrtf(var + eps);
     typename Opnd<T>::E* o = out + ((size_t)b * T0 + t) * 512;
-    store_opnd1<T>(o + oa, lo_off, act_apply(xa[tt] * rstd * ga + ea, ACT_GELU_ERF));      // (split kind: hi plane here, lo plane lo_off elements on)
-    store_opnd1<T>(o + ob, lo_off, act_apply(xb[tt] * rstd * gb + eb, ACT_GELU_ERF));
+    store_opnd1<T>(o + oa, lo_off, act_apply_t<T>(xa[tt] * rstd * ga + ea, ACT_GELU_ERF));      // (split kind: hi plane here, lo plane lo_off elements on)
+    store_opnd1<T>(o + ob, lo_off, act_apply_t<T>(xb[tt] * rstd * gb + eb, ACT_GELU_ERF));
   }
 }
 
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(1024) void time_groupnorm_kernel(const float* x, co
   if (!ok) return;
   const float gm = gamma ? gamma[ch] : 1.f, bt = beta ? beta[ch] : 0.f;
   for (int t = tl; t < Tn; t += 16) {
-    const float v = act_apply((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
+    const float v = act_apply_t<T>((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
     const size_t o = ((size_t)b * Tn + t) * C + ch;
     if (y_f32) y_f32[o] = v;
     if (y_t) store_opnd1<T>(y_t + o, lo_off, v);
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(1024) void time_norm_apply_kernel(const float* x, c
   const float* xp = x + (size_t)b * Tn * C + ch;
   const int t1 = min(Tn, (c + 1) * chunk);
   for (int t = c * chunk + tl; t < t1; t += 16) {
-    const float v = act_apply((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
+    const float v = act_apply_t<T>((xp[(size_t)t * C] - mean) * rstd * gm + bt, act);
     const size_t o = ((size_t)b * Tn + t) * C + ch;
     if (y_f32) y_f32[o] = v;
     if (y_t) store_opnd1<T>(y_t + o, lo_off, v);

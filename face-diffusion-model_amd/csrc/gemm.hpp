@@ -119,7 +119,7 @@ template <bool HEAVY, typename T> __device__ __forceinline__ float gemm_act(floa
       const float c = 0.7978845608028654f * (v + 0.044715f * v * v * v);
       return v * (0.5f * (2.f - 2.f / (1.f + __expf(2.f * c))));
     }
-    return act_apply(v, act);
+    return act_apply_t<T>(v, act);      // (GELU(erf): the fast form too)
   } else {
     return act_apply(v, act);     // fp32 and split (parity) modes: accurate libm forms
   }

@@ -521,7 +521,7 @@ def test_small_ops():
     assert T0 % 16 and rel(o, ref) < 1e-5
     ob = torch.zeros(2, T0, 512, device=DEV, dtype=torch.bfloat16)
     ops.conv0_ln_gelu(wav.to(DEV), w0.to(DEV), b0.to(DEV), gam.to(DEV), bet.to(DEV), ob, 2, 4000, T0)
-    assert torch.equal(ob, o.to(torch.bfloat16))
+    assert float((ob.float() - o).abs().max()) <= 2 ** -8 * float(o.abs().max()) + 1e-6      # (the bf16 kind uses the fast GELU: within one bf16 ulp of the fp32 form)
     # leaky + instance norm
     xi = torch.randn(2, 37, 1024, generator=g)
     o = torch.zeros(2, 37, 1024, device=DEV)
@@ -720,5 +720,5 @@ def test_time_groupnorm_single_launch_and_chunked_forms():
             outs.append(o)
         ob = torch.zeros(B, T, C, device=DEV, dtype=torch.bfloat16)
         ops.time_groupnorm(x.to(DEV), gam.to(DEV), bet.to(DEV), B, T, C, y_t=ob, act=ACT_GELU_ERF, dtype=ops.code_of(ob), scratch=scratch)
-        assert torch.equal(ob, outs[1].to(torch.bfloat16))
+        assert float((ob.float() - outs[1]).abs().max()) <= 2 ** -8 * float(outs[1].abs().max()) + 1e-6
     torch.cuda.synchronize()
