@@ -403,16 +403,25 @@ typedef struct fdm_sample_args {
 } fdm_sample_args;
 int fdm_sample_graph(fdm_plan* p, const fdm_sample_args* a, void* stream);
 /* Plan-time tuning of the GEMM output tiles at the prepared shape (times candidates per call site; changes speed only, every
- * tile accumulates k in the same order).  Besides this call, fdm_audio_prepare tunes a shape that earlier sampling calls have
- * run >= 2000 diffusion steps at; fdm_sample_graph never tunes unless fdm_plan_set(p, "tune_lazy", 1).  FDM_TUNE=0 disables
- * the tuner; FDM_TILE_OVERRIDE="qkv=3,ffn1=2" pins call sites (applied at fdm_audio_prepare, with or without the tuner).
- * FDM_TILE_CACHE=<file> (opt-in) keeps tuned sets across processes: a tuning run appends "<version|mode|geometry|shape>\t<site>=<tile>,..."
- * (temporary file + rename), and fdm_audio_prepare takes a stored set for its shape without any timing launch. */
+ * tile accumulates k in the same order).  This call is the ONLY place the library tunes by itself: request paths
+ * (fdm_audio_prepare*, fdm_sample_graph) never do -- fdm_plan_get(p, "needs_tune") turns 1 once the prepared shape has served
+ * >= 2000 diffusion steps on heuristic tiles, so a serving caller can schedule this call off the request path.  Opt-in
+ * (fdm_plan_set(p, "tune_lazy", 1)): tune inside fdm_audio_prepare* / fdm_sample_graph once that is the case; a tuner failure
+ * there keeps the heuristic tiles and is counted ("tune_failed"), it never fails the request.
+ * The library reads five environment variables, all about tiles: FDM_TUNE=0 disables the tuner (heuristic tiles, or the pinned
+ * set); FDM_TUNE_VERBOSE=1 prints its choices; FDM_TILE_OVERRIDE="qkv=3,ffn1=2" pins call sites (applied at fdm_audio_prepare*,
+ * with or without the tuner); FDM_TILE_CACHE=<file> (opt-in) keeps tuned sets across processes: a tuning run appends
+ * "<version|mode|geometry|shape>\t<site>=<tile>,..." (temporary file + rename), and fdm_audio_prepare* takes a stored set for its
+ * shape without any timing launch; FDM_GEMM_TILE=<FDM_TILE_*> forces one tile for every fdm_op_gemm with tile = 0 (A/B sweeps). */
 int fdm_plan_tune(fdm_plan* p, void* stream);
 /* Introspection / experiments: integer properties by name -- "launches_per_step", "graph_launches" (host graph launches of
- * the last fdm_sample_graph), "fuse_ln3", "rows", "tile.<call site>" (qkv, out, ffn1, ffn2, enc, dec, ...). */
+ * the last fdm_sample_graph), "rows", "tuned", "needs_tune", "tune_failed", "fuse_ln3", "tile.<call site>" (qkv, out, ffn1, ffn2,
+ * enc, dec, ...). */
 int fdm_plan_get(fdm_plan* p, const char* key, long long* out);
-int fdm_plan_set(fdm_plan* p, const char* key, long long value);    /* "tile.<call site>" (drops recorded programs), "tune" (0 = off), "tune_lazy" (1 = in-call tuning allowed) */
+/* "tile.<call site>" (drops recorded programs), "tune" (0 = off), "tune_lazy" (1 = in-call tuning allowed), "untune" (forget every
+ * tuned set), "fuse_ln3" (1 = fold norm3 into the GEMMs around it: 8 launches fewer per step, no longer faster; takes effect at
+ * the next commit) */
+int fdm_plan_set(fdm_plan* p, const char* key, long long value);
 
 /* ------------------------------------------------------------------------------------------
  * Audio encoder (once per clip: it does not depend on (t, x_t), so the reference's per-step re-run, models/fdm_vocaset.py:59,
