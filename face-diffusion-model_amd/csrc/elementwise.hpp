@@ -259,61 +259,59 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, const floa
 }
 
 // The same layer with its LayerNorm(512) + GELU(erf) applied before anything is stored (HuBERT-large, feat_extract_norm = 'layer':
-// transformers HubertLayerNormConvLayer): a workgroup holds the 512 channels of 16 frames in registers (2 channels x 16 frames per
-// thread), so the two-pass statistics of every frame are two block reductions for all 16 frames at once and only the operand
-// copy leaves the chip -- 128 MB instead of 250 MB written + 250 MB read + 128 MB written at 4 x 10 s (round 4: 88 + 99 us ->
-// one kernel).
+// transformers HubertLayerNormConvLayer).  ONE WAVE PER FRAME: a lane owns 8 adjacent channels (its 80 filter taps stay in
+// registers for all the frames the wave handles), so a frame's two-pass statistics are two wave reductions -- no LDS, no workgroup
+// barrier -- the ten waveform samples of a frame are wave-uniform (scalar loads), and a lane stores its 8 outputs as whole 16-byte
+// (bf16) / 2 x 16-byte (fp32, fp16 plane pair) accesses.  Only the operand copy leaves the chip: 128 MB instead of 250 MB written +
+// 250 MB read + 128 MB written at 4 x 10 s.  (Round 4: conv0 + LayerNorm kernels 88 + 99 us; first fused form -- 2 channels x 16
+// frames per thread, 2-byte stores -- 128-143 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* wav, const float* w, const float* bias, const float* gamma,
                                                             const float* beta, typename Opnd<T>::E* out, long long lo_off, int n, int T0, float eps) {
-  constexpr int TT = 16;
-  __shared__ float red[2][TT][4];
+  constexpr int FPW = 8;                      // frames per wave; a workgroup of 4 waves covers 32 consecutive frames
   const int b = blockIdx.y;
-  const int t0 = blockIdx.x * TT;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c0 = lane * 8;
   const float* wv = wav + (size_t)b * n;
-  const int oa = threadIdx.x, ob = threadIdx.x + 256, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float wa[10], wb[10];
+  float wt[8][10], bs[8], ga[8], be[8];
 #pragma unroll
-  for (int k = 0; k < 10; ++k) { wa[k] = w[oa * 10 + k]; wb[k] = w[ob * 10 + k]; }
-  const float ba = bias ? bias[oa] : 0.f, bb = bias ? bias[ob] : 0.f;
-  float xa[TT], xb[TT];
+  for (int c = 0; c < 8; ++c) {
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const int t = min(t0 + tt, T0 - 1);
-    float a = 0.f, c = 0.f;
-#pragma unroll
-    for (int k = 0; k < 10; ++k) {
-      const float x = wv[5 * t + k];
-      a = fmaf(wa[k], x, a);
-      c = fmaf(wb[k], x, c);
-    }
-    xa[tt] = a + ba; xb[tt] = c + bb;
+    for (int k = 0; k < 10; ++k) wt[c][k] = w[(c0 + c) * 10 + k];
+    bs[c] = bias ? bias[c0 + c] : 0.f;
+    ga[c] = gamma[c0 + c]; be[c] = beta[c0 + c];
   }
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const float s = wave_sum(xa[tt] + xb[tt]);
-    if (lane == 0) red[0][tt][wave] = s;
-  }
-  __syncthreads();
-  float mean[TT];
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    mean[tt] = ((red[0][tt][0] + red[0][tt][1]) + (red[0][tt][2] + red[0][tt][3])) * (1.f / 512.f);
-    xa[tt] -= mean[tt]; xb[tt] -= mean[tt];
-    const float q = wave_sum(xa[tt] * xa[tt] + xb[tt] * xb[tt]);
-    if (lane == 0) red[1][tt][wave] = q;
-  }
-  __syncthreads();
-  const float ga = gamma[oa], gb = gamma[ob], ea = beta[oa], eb = beta[ob];
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const int t = t0 + tt;
+  const int f0 = (blockIdx.x * 4 + wave) * FPW;
+  for (int f = 0; f < FPW; ++f) {
+    const int t = f0 + f;                     // (wave-uniform)
     if (t >= T0) break;
-    const float var = ((red[1][tt][0] + red[1][tt][1]) + (red[1][tt][2] + red[1][tt][3])) * (1.f / 512.f);
-    const float rstd = 1.f / sqrtf(var + eps);
-    typename Opnd<T>::E* o = out + ((size_t)b * T0 + t) * 512;
-    store_opnd1<T>(o + oa, lo_off, act_apply_t<T>(xa[tt] * rstd * ga + ea, ACT_GELU_ERF));      // (split kind: hi plane here, lo plane lo_off elements on)
-    store_opnd1<T>(o + ob, lo_off, act_apply_t<T>(xb[tt] * rstd * gb + eb, ACT_GELU_ERF));
+    float x[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) x[k] = wv[5 * t + k];
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) a = fmaf(wt[c][k], x[k], a);
+      v[c] = a + bs[c];
+    }
+    s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    const float mean = wave_sum(s) * (1.f / 512.f);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { v[c] -= mean; q += v[c] * v[c]; }
+    const float rstd = 1.f / sqrtf(wave_sum(q) * (1.f / 512.f) + eps);
+    f32x4 y0, y1;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      y0[c] = act_apply_t<T>(v[c] * rstd * ga[c] + be[c], ACT_GELU_ERF);
+      y1[c] = act_apply_t<T>(v[c + 4] * rstd * ga[c + 4] + be[c + 4], ACT_GELU_ERF);
+    }
+    typename Opnd<T>::E* o = out + ((size_t)b * T0 + t) * 512 + c0;
+    store_opnd4<T>(o, lo_off, y0);
+    store_opnd4<T>(o + 4, lo_off, y1);
   }
 }
 

@@ -294,7 +294,7 @@ int fdm_op_conv0_ln_gelu(const float* wav, const float* w, const float* bias, co
   if (dtype != FDM_F32 && dtype != FDM_BF16 && dtype != FDM_F16X3) return fail(FDM_ERR_ARG, "conv0_ln_gelu: dtype %d (fp32, bf16 or FDM_F16X3 output)", dtype);
   if (dtype == FDM_F16X3 && out_lo_off <= 0) return fail(FDM_ERR_ARG, "conv0_ln_gelu: split output needs out_lo_off");
   return submit([=](hipStream_t s) {
-    const dim3 grid((T0 + 15) / 16, B);
+    const dim3 grid((T0 + 31) / 32, B);       // 4 waves x 8 frames per workgroup
     if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<fdm::bf16>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (fdm::bf16*)out, 0LL, n, T0, eps);
     else if (dtype == FDM_F16X3) hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<fdm::f16x3_t>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (fdm::f16*)out, out_lo_off, n, T0, eps);
     else hipLaunchKernelGGL((fdm::conv0_ln_gelu_kernel<float>), grid, dim3(256), 0, s, wav, w, bias, gamma, beta, (float*)out, 0LL, n, T0, eps);
