@@ -522,6 +522,9 @@ def test_small_ops():
     ob = torch.zeros(2, T0, 512, device=DEV, dtype=torch.bfloat16)
     ops.conv0_ln_gelu(wav.to(DEV), w0.to(DEV), b0.to(DEV), gam.to(DEV), bet.to(DEV), ob, 2, 4000, T0)
     assert float((ob.float() - o).abs().max()) <= 2 ** -8 * float(o.abs().max()) + 1e-6      # (the bf16 kind uses the fast GELU: within one bf16 ulp of the fp32 form)
+    sp = ops.Split.empty(2 * T0, 512, F16X3, DEV)                                               # split-fp16 plane pair (contract-mode encoder front)
+    ops.conv0_ln_gelu(wav.to(DEV), w0.to(DEV), b0.to(DEV), gam.to(DEV), bet.to(DEV), sp, 2, 4000, T0)
+    assert float((sp.float().reshape(2, T0, 512) - o).abs().max()) <= 1e-6 * max(1.0, float(o.abs().max()))
     # leaky + instance norm
     xi = torch.randn(2, 37, 1024, generator=g)
     o = torch.zeros(2, 37, 1024, device=DEV)
@@ -721,4 +724,9 @@ def test_time_groupnorm_single_launch_and_chunked_forms():
         ob = torch.zeros(B, T, C, device=DEV, dtype=torch.bfloat16)
         ops.time_groupnorm(x.to(DEV), gam.to(DEV), bet.to(DEV), B, T, C, y_t=ob, act=ACT_GELU_ERF, dtype=ops.code_of(ob), scratch=scratch)
         assert float((ob.float() - outs[1]).abs().max()) <= 2 ** -8 * float(outs[1].abs().max()) + 1e-6
+        # split-fp16 plane pair (the contract-mode encoder front): hi + lo / 2^11 reproduces the fp32 output to ~2^-22, both forms
+        for sc in (None, scratch):
+            sp = ops.Split.empty(B * T, C, F16X3, DEV)
+            ops.time_groupnorm(x.to(DEV), gam.to(DEV), bet.to(DEV), B, T, C, y_t=sp, act=ACT_GELU_ERF, dtype=F16X3, scratch=sc)
+            assert float((sp.float().reshape(B, T, C) - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max())), (B, T, C, sc is not None)
     torch.cuda.synchronize()
