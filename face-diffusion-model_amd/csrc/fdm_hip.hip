@@ -82,7 +82,7 @@ int grid_for(long long n) {
 extern "C" {
 
 const char* fdm_last_error(void) { return g_err.c_str(); }
-int fdm_version(void) { return 103; }      // 1.03: round 3 (fdm_audio_prepare_conds, fdm_vq_quant_stats, fdm_ln_args row map)
+int fdm_version(void) { return 104; }      // 1.04: round 4 (fdm_op_conv0_ln_gelu, fdm_op_time_groupnorm scratch + split outputs, FDM_TILE_GENERAL, 96x128 retired, needs_tune)
 
 // sizeof() of a public struct as THIS build sees it: a binding compares it with its own mirror before the first call
 int fdm_abi_struct_size(const char* name) {
