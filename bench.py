@@ -210,6 +210,8 @@ def main():
     ap.add_argument("--broadcast-weights", action="store_true",
                     help="N > 1: rank 0's weights are broadcast to every rank (one flattened RCCL broadcast, outside the timed region) "
                          "instead of each rank generating its own copy from the seed")
+    ap.add_argument("--plan-set", action="append", default=[], metavar="KEY=VALUE",
+                    help="fdm_plan_set on every denoiser plan of the run before its tables are built, e.g. ksplit.out=2, fuse_ln3=1 (A/B measurements)")
     ap.add_argument("--dump", default="", help="tests only: rank 0 saves the gathered output of the last call to this .npy file")
     a = ap.parse_args()
 
@@ -259,6 +261,12 @@ def main():
     if S > 1:                                               # every style one-hot of each clip; all conditions start from the clip's x_T
         style = torch.eye(p.n_style)[:S].repeat(B, 1)
         xT = xT.repeat_interleave(S, dim=0)
+    # one clip, one condition per call (the reference's bs = 1 callers): the step program's single-clip setting -- K slices of the
+    # out-proj / FFN2 GEMMs summed by the LayerNorm launch that follows (fdm_amd/modules.py SINGLE_CLIP_PLAN)
+    from fdm_amd.modules import SINGLE_CLIP_PLAN
+    plan_opts = dict(SINGLE_CLIP_PLAN) if (B == 1 and S == 1) else {}
+    for kv in a.plan_set:
+        plan_opts[kv.split("=", 1)[0]] = int(kv.split("=", 1)[1])
     shipped = SHIPPED.get(a.config)                         # the reference callers' per-clip workload, end to end
     e2e = a.config == "cfg5" or shipped is not None
     if shipped:
@@ -303,6 +311,8 @@ def main():
         """One arithmetic mode of the configuration: plan, tables, plan-time tuning, the timed calls, parity of the same plan."""
         dt = DTYPE_NAMES[dtype_name]
         plan = DenoiserPlan(preset, weights, dt, dev)
+        for k, v in plan_opts.items():
+            plan.set(k, v)
         hub_plan = vq_plan = wav = None
         if e2e:
             from fdm_amd.hubert import WAV2VEC2_BASE, HubertPlan
@@ -524,6 +534,7 @@ def main():
             "host_graph_launches_per_sample": head["host_graph_launches_per_sample"],
             "denoiser_steps_per_sample": head["denoiser_steps_per_sample"],
             "gemm_tiles": head["gemm_tiles"],
+            "plan_options": plan_opts,
             "roofline": head["roofline"],
         }
         for k in ("roofline_hbm", "stages_ms", "sequential_loop", "speedup_vs_sequential_loop", "shard_check"):

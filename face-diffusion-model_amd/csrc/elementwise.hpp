@@ -28,6 +28,11 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
   // all instead of one per operand (the kernel is launch-to-launch latency, not bandwidth)
   const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
   f32x4 v = *(const f32x4*)(p.x + (size_t)row * d + col);
+  // split-K partial planes of the row (fdm_gemm_args.ksplit): requested with everything else, summed in plane order below
+  const int npl = p.x_planes;
+  f32x4 vpl[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) vpl[i] = (i + 1 < npl) ? *(const f32x4*)(p.x + (size_t)(i + 1) * p.x_plane_stride + (size_t)row * d + col) : zero;
   const bool has_e = p.add_mat || p.add_tab;
   int arow = row;                      // (uniform: scalar arithmetic) conditions of a clip share the clip's addend rows
   if (p.add_mat_group > 0) {
@@ -54,6 +59,9 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
     for (int w = 0; w < NV; ++w) t += red[slot][w];
     return t;
   };
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (i + 1 < npl) v += vpl[i];
   if (!two && has_e) v += e;
   float mean = block_sum((v[0] + v[1]) + (v[2] + v[3]), 0) * (1.f / d);
   v -= mean;

@@ -148,6 +148,20 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
     if (sc.mode == 1 && (!sc.sra || !sc.srm1 || !sc.sqrt_an || !sc.c_n)) return fail(FDM_ERR_ARG, "gemm: fused DDIM needs sra, srm1, sqrt_an, c_n");
     if (sc.mode == 0 && !sc.noise && sc.n_per_clip <= 0) return fail(FDM_ERR_ARG, "gemm: fused DDPM with Philox noise needs n_per_clip");
   }
+  if (a->ksplit < 0 || a->ksplit > 4) return fail(FDM_ERR_ARG, "gemm: ksplit %d outside 0..4", a->ksplit);
+  if (a->ksplit > 1) {
+    const int tl = a->tile & ~FDM_TILE_GENERAL;
+    if (a->dtype == FDM_BF16X3) return fail(FDM_ERR_ARG, "gemm: ksplit is not offered for the bf16x3 comparison kind");
+    if (a->batch > 1 || a->out_batch_stride || a->act != FDM_ACT_NONE || !a->out_f32 || a->out_t || a->out_kp || a->out_vp || a->stat_out || a->ln_stat_in ||
+        a->sched_fuse || a->resid_row_mod || (a->tile & FDM_TILE_GENERAL))
+      return fail(FDM_ERR_ARG, "gemm: ksplit needs a plain launch (one batch, no activation, out_f32 as the only output, no folds)");
+    if ((a->K / bk) % a->ksplit) return fail(FDM_ERR_SHAPE, "gemm: ksplit %d does not divide the %d k-tiles of K=%d", a->ksplit, a->K / bk, a->K);
+    if (a->N % 64 || a->ldo_f32 % 4 || !aligned16(a->out_f32) || a->ksplit_stride % 4 || a->ksplit_stride < (long long)(a->M - 1) * a->ldo_f32 + a->N ||
+        (a->resid && (a->ldr % 4 || !aligned16(a->resid))))
+      return fail(FDM_ERR_SHAPE, "gemm: ksplit needs N %% 64 == 0, 16-byte aligned rows and ksplit_stride >= one output plane");
+    if (tl != 0 && tl != FDM_TILE_64x64 && tl != FDM_TILE_64x64_S3 && tl != FDM_TILE_64x64_S2 && tl != FDM_TILE_32x64_S3)
+      return fail(FDM_ERR_ARG, "gemm: ksplit runs on the 64-column tiles (FDM_TILE_64x64, _S3, _S2, FDM_TILE_32x64_S3), not tile %d", tl);
+  }
   fdm_gemm_args c = *a;
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
 }
@@ -196,6 +210,8 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
   if (a->add_mat_group < 0 || a->add_mat_wrap < 0 ||
       (a->add_mat_group > 0 && (a->add_mat_L <= 0 || a->add_mat_group % a->add_mat_L || (a->add_mat_wrap > 0 && a->add_mat_wrap % a->add_mat_group))))
     return fail(FDM_ERR_SHAPE, "layernorm: shared add_mat needs add_mat_L | add_mat_group | add_mat_wrap (got %d, %d, %d)", a->add_mat_L, a->add_mat_group, a->add_mat_wrap);
+  if (a->x_planes < 0 || a->x_planes > 4 || (a->x_planes > 1 && (a->x_plane_stride < (long long)a->M * a->d || a->x_plane_stride % 4)))
+    return fail(FDM_ERR_ARG, "layernorm: x_planes %d (0..4) needs x_plane_stride >= M * d, a multiple of 4", a->x_planes);
   fdm_ln_args c = *a;
   return submit([c](hipStream_t s) {
     switch (c.dtype) {

@@ -131,7 +131,22 @@ __host__ __device__ inline bool gemm_act_is_heavy(int act) { return act == ACT_M
 // instruction fetch -- is not compiled in.
 // SPEC further says what the launch can need: GEMM_KV = packed K / V outputs, GEMM_FOLD = the LayerNorm-folding producer /
 // consumer forms; a lean kernel without either is bias + activation + residual + stores (a few hundred instructions).
-constexpr int GEMM_LEAN = 1, GEMM_KV = 2, GEMM_FOLD = 4;
+constexpr int GEMM_LEAN = 1, GEMM_KV = 2, GEMM_FOLD = 4, GEMM_KSPLIT = 8;
+// GEMM_KSPLIT (with GEMM_LEAN): blockIdx.z is a K slice, not a batch index -- slice s runs k-tiles [s nk / S, (s + 1) nk / S) and
+// stores its fp32 partial tile to plane s of out_f32; slice 0 alone adds bias and residual (fdm_gemm_args.ksplit).  The
+// epilogue sees the slice's view of the arguments:
+template <bool KSP> struct KSliceArgs;
+template <> struct KSliceArgs<false> {
+  const fdm_gemm_args& a;
+  __device__ __forceinline__ KSliceArgs(const fdm_gemm_args& p, int) : a(p) {}
+};
+template <> struct KSliceArgs<true> {
+  fdm_gemm_args a;
+  __device__ __forceinline__ KSliceArgs(const fdm_gemm_args& p, int slice) : a(p) {
+    a.out_f32 = p.out_f32 + (size_t)slice * p.ksplit_stride;
+    if (slice > 0) { a.bias = nullptr; a.resid = nullptr; }
+  }
+};
 template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true, bool SCHED = false, int SPEC = 0>
 __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&acc)[BM / WM / 16][BN / WN / 16],
                                               const EpiPre<BM / WM / 16, BN / WN / 16>& e, int m0, int n0, int z,
@@ -434,11 +449,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r16 = lane & 15;
-  const int z = blockIdx.z;
+  constexpr bool KSP = (SPEC & GEMM_KSPLIT) != 0;
+  const int z = KSP ? 0 : blockIdx.z;            // batch index (a K-sliced launch is not batched)
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int M = p.M, N = p.N;
+  constexpr int EPC = 16 / (int)sizeof(E);
+  int nk = p.K / (KCH * EPC);
   const E* A = (const E*)p.A + (size_t)z * p.a_batch_stride;
   const E* W = (const E*)p.W + (size_t)z * p.w_batch_stride;
+  if constexpr (KSP) {                           // this slice's k-tiles: [slice * nk, (slice + 1) * nk)
+    nk /= p.ksplit;
+    A += (size_t)blockIdx.z * nk * (KCH * EPC);
+    W += (size_t)blockIdx.z * nk * (KCH * EPC);
+  }
+  const KSliceArgs<KSP> ksa(p, blockIdx.z);
+  const fdm_gemm_args& pe = ksa.a;               // what the epilogue reads (bias, residual, outputs)
   const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);   // bytes hi plane -> lo plane
 
   // per-lane source pointers (k-tile 0, plane 0); LDS row groups are wave-uniform.  The LDS image is
@@ -491,14 +516,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   // wait of the kernel); the epilogue operands follow, younger than those tiles and older than every later one: the counted
   // waits of the first k iterations are stricter by their number until they have returned, and the loop's final vmcnt(0)
   // covers them in any case.
-  constexpr int EPC = 16 / (int)sizeof(E);
-  const int nk = p.K / (KCH * EPC);
 #pragma unroll
   for (int t = 0; t < NST - 1; ++t)
     if (t < nk) issue(t);
   EpiPre<MI, NI> epre;
   constexpr bool FOLDC = !(SPEC & GEMM_LEAN) || (SPEC & GEMM_FOLD);
-  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(p, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
+  gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(pe, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
   if constexpr (FOLDC) gemm_load_rowstats<BM>(p, m0, rowstat);   // visible to every wave after the first barrier of the k loop
 
   // fragment (plane pl, k-step s) of tile row `row` in the stage at `base`: one ds_read_b128 through the XOR swizzle
@@ -583,7 +606,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #ifdef FDM_GEMM_STAMPS
   if (stamps && tid == 0) stamps[2] = wall_clock64();
 #endif
-  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(p, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+  gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(pe, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 #ifdef FDM_GEMM_STAMPS
   if (stamps && tid == 0) stamps[3] = wall_clock64();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -868,7 +891,7 @@ static hipError_t gemm_pp_launch_h(const fdm_gemm_args& a, hipStream_t s) {
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false, int SPEC = 0>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.batch > 0 ? a.batch : 1);
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, (SPEC & GEMM_KSPLIT) ? a.ksplit : (a.batch > 0 ? a.batch : 1));
   constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
   static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
   static bool once = [] {
@@ -900,6 +923,14 @@ static bool gemm_all_tiles_lean(const fdm_gemm_args& a) {
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
 static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
   const bool no_lean = (a.tile & FDM_TILE_GENERAL) != 0;      // tests: the edge-handling kernel on a shape that does not need it
+  if (a.ksplit > 1) {       // K-sliced launch (validated by fdm_op_gemm: plain fp32 output, no activation): the 64-column tiles only
+    if constexpr (BN == 64 && (BM == 64 || BM == 32)) {
+      if (!gemm_all_tiles_lean<T, BM, BN>(a)) return hipErrorInvalidValue;
+      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KSPLIT>(a, s);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (gemm_act_is_heavy(a.act)) {
     if (!no_lean && !a.out_kp && !a.out_vp && !a.stat_out && !a.ln_stat_in && gemm_all_tiles_lean<T, BM, BN>(a))
       return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_LEAN>(a, s);
@@ -1007,6 +1038,19 @@ static bool gemm_sched_fuse_heuristic_pp(const fdm_gemm_args& a, int elem_bytes)
   return gemm_heuristic_tile(b, elem_bytes, false) == FDM_TILE_256x128_PP;
 }
 
+// K-sliced launches (fdm_gemm_args.ksplit): the 64-column tiles, ring depth by tile id.  With S slices per output tile the grid
+// is S times as large and a slice's chain 1 / S as long, so shallower rings (more co-resident slices per CU) are the candidates.
+static int gemm_ksplit_heuristic_tile(const fdm_gemm_args& a) { return a.M <= 128 ? FDM_TILE_32x64_S3 : FDM_TILE_64x64; }   // (profiles/r5_splitk/)
+template <typename T>
+static hipError_t gemm_dispatch_ksplit(const fdm_gemm_args& a, int tile_id, hipStream_t s) {
+  switch (tile_id > 0 ? tile_id : gemm_ksplit_heuristic_tile(a)) {
+    case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);
+    case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);
+    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);
+    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);
+  }
+}
+
 template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   if (a.sched_fuse) {     // (validated: interior tiles only -> the lean epilogue)
@@ -1019,6 +1063,7 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
                         : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
   }
   const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+  if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
   const int want = tile_id > 0 ? tile_id : gemm_tile_override();
   switch (want > 0 ? want : gemm_heuristic_tile(a, (int)sizeof(typename Opnd<T>::E), false)) {
     case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
@@ -1047,6 +1092,7 @@ static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
     return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                          // comparison mode: one tile
   } else {
     const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+    if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
     const int want = tile_id > 0 ? tile_id : gemm_tile_override();
     switch (want > 0 ? want : gemm_heuristic_tile(a, 2, true)) {
       case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);  // 96 KB

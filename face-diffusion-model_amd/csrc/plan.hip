@@ -235,6 +235,10 @@ struct fdm_plan {
   int tune_enabled = 1;
   int tune_failed = 0;                       // opt-in request-path tuning runs that failed (heuristic tiles kept)
   int want_fuse_ln3 = 0;                     // fdm_plan_set "fuse_ln3": fold norm3 into the GEMMs around it at the next commit
+  // K slices of the two GEMMs whose fp32 output row is read next by a LayerNorm launch (out-proj -> LN1+LN2, FFN2 -> LN3): S > 1 = S
+  // partial planes of x1, summed by that launch (fdm_gemm_args.ksplit / fdm_ln_args.x_planes).  A property of the plan, NOT of the
+  // shape: results depend on S, and a clip must compute the same bits in every batch composition.
+  int ksplit_out = 1, ksplit_ffn2 = 1;
   int tune_lazy = 0;                         // 1: fdm_sample_graph may tune in-call once a shape has run 2000 steps (opt-in)
   long long last_graph_launches = 0, launches_per_step = 0;
 };
@@ -506,7 +510,7 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   const fdm_model_desc& m = P->m;
   const size_t d = m.d, M = (size_t)B * L, R = M * repc;
   const size_t Lpad = ((size_t)L + 31) / 32 * 32;
-  FCK(dalloc_t(P, &P->h, R * d, true)); FCK(dalloc_t(P, &P->h2, R * d, true)); FCK(dalloc_t(P, &P->x1, R * d, true));
+  FCK(dalloc_t(P, &P->h, R * d, true)); FCK(dalloc_t(P, &P->h2, R * d, true)); FCK(dalloc_t(P, &P->x1, R * d * 4, true));      // (x1: up to four split-K partial planes)
   FCK(dalloc_t(P, &P->x0, R * d, true)); FCK(dalloc_t(P, &P->x, M * d, true));
   if (P->dtype != FDM_F32) {
     FCK(dalloc_mat(P, &P->xt, M, d, true)); FCK(dalloc_mat(P, &P->ht, R, d, true)); FCK(dalloc_mat(P, &P->h2t, R, d, true));
@@ -600,6 +604,7 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
     g.bias = b; g.out_f32 = P->x1;
     if (!f) {
       g.resid = P->h;
+      if (P->ksplit_out > 1) { g.ksplit = P->ksplit_out; g.ksplit_stride = (long long)R * d; }
       FCK(plan_gemm(P, "out", g, stream));
     } else {
       g.resid = P->x2; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.rln_gamma = f->gamma; g.rln_beta = f->beta;
@@ -610,6 +615,7 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
     memset(&ln, 0, sizeof(ln));
     ln.x = P->x1; ln.M = R; ln.d = d; ln.add_mat = P->C1[l]; ln.add_tab = P->TT[l]; ln.tab_step = tcur; ln.eps = eps;
     if (P->S > 1) { ln.add_mat_L = L; ln.add_mat_group = P->S * L; ln.add_mat_wrap = M; }     // C1_l holds one block per audio clip
+    if (!f && P->ksplit_out > 1) { ln.x_planes = P->ksplit_out; ln.x_plane_stride = (long long)R * d; }
     FCK(need(P, lname(l, "norm1.weight"), d, &ln.gamma)); FCK(need(P, lname(l, "norm1.bias"), d, &ln.beta));
     FCK(need(P, lname(l, "norm2.weight"), d, &ln.gamma2)); FCK(need(P, lname(l, "norm2.bias"), d, &ln.beta2));
     ln.y_f32 = P->h2; ln.dtype = P->dtype;
@@ -627,9 +633,11 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
       FCK(plan_gemm(P, "ffn2_stat", g, stream));
     } else {
       g.out_f32 = P->x1;
+      if (P->ksplit_ffn2 > 1) { g.ksplit = P->ksplit_ffn2; g.ksplit_stride = (long long)R * d; }
       FCK(plan_gemm(P, "ffn2", g, stream));
       memset(&ln, 0, sizeof(ln));
       ln.x = P->x1; ln.M = R; ln.d = d; ln.eps = eps; ln.y_f32 = P->h; ln.dtype = P->dtype;
+      if (P->ksplit_ffn2 > 1) { ln.x_planes = P->ksplit_ffn2; ln.x_plane_stride = (long long)R * d; }
       FCK(need(P, lname(l, "norm3.weight"), d, &ln.gamma)); FCK(need(P, lname(l, "norm3.bias"), d, &ln.beta));
       if (both) { ln.y_t = P->ht.p; ln.y_t_lo_off = P->ht.lo; }
       FCK(fdm_op_layernorm(&ln, stream));
@@ -670,6 +678,7 @@ std::string tiles_sig(const fdm_plan* P) {
   std::string s;
   for (auto& kv : P->tiles)
     if (kv.second) s += kv.first + "=" + std::to_string(kv.second) + ",";
+  s += "ks" + std::to_string(P->ksplit_out) + std::to_string(P->ksplit_ffn2);
   return s;
 }
 
@@ -992,6 +1001,7 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
     const int heur = launched(fdm_gemm_heuristic_tile(&kv.second[0]));
     for (int tile : cands) {
       if (launched(tile) == heur) continue;
+      if (kv.second[0].ksplit > 1 && tile != FDM_TILE_64x64 && tile != FDM_TILE_64x64_S3 && tile != FDM_TILE_64x64_S2 && tile != FDM_TILE_32x64_S3) continue;   // K-sliced sites
       if (kv.second[0].sched_fuse && tile != FDM_TILE_256x128_PP && tile != FDM_TILE_64x64) continue;      // the scheduler-fused decoder has two forms: 64x64 and the ping-pong tile
       if (modelled_us(kv.second[0], tile) > 1.35 * best_model) continue;
       float t = 0.f;
@@ -1318,6 +1328,8 @@ int fdm_plan_get(fdm_plan* P, const char* key, long long* out) {
   else if (k == "graph_launches") *out = P->last_graph_launches;
   else if (k == "fuse_ln3") *out = P->fuse_ln3;
   else if (k == "rows") *out = P->R;
+  else if (k == "ksplit.out") *out = P->ksplit_out;
+  else if (k == "ksplit.ffn2") *out = P->ksplit_ffn2;
   else if (k == "tuned") *out = P->tile_cache.count(shape_key(P)) ? 1 : 0;
   else if (k == "needs_tune") { const std::string sk = shape_key(P); *out = (!P->tile_cache.count(sk) && P->tune_enabled && P->steps_seen.count(sk) && P->steps_seen[sk] >= 2000) ? 1 : 0; }
   else if (k == "tune_failed") *out = P->tune_failed;
@@ -1334,6 +1346,16 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
   if (k == "fuse_ln3") {      // takes effect at the next commit (the folded weights are commit-time tables)
     if ((value != 0) != (P->want_fuse_ln3 != 0)) { P->want_fuse_ln3 = value != 0; P->committed = false; P->prepared = false; return drop_programs(P, nullptr); }
     return FDM_OK;
+  }
+  if (k == "ksplit.out" || k == "ksplit.ffn2") {      // K slices of the out-proj / FFN2 GEMMs (1 = none); tuned tiles of other split factors no longer apply
+    const int kt = (k == "ksplit.out" ? P->m.d : P->m.ffn) / (P->dtype == FDM_F32 ? 32 : 64);
+    if (value < 1 || value > 4 || kt % value) return fail(FDM_ERR_ARG, "plan_set: %s = %lld must be 1..4 and divide the %d k-tiles", key, value, kt);
+    if (P->dtype == FDM_BF16X3 && value > 1) return fail(FDM_ERR_ARG, "plan_set: %s is not offered for the bf16x3 comparison kind", key);
+    int& cur = k == "ksplit.out" ? P->ksplit_out : P->ksplit_ffn2;
+    if (cur == (int)value) return FDM_OK;
+    cur = (int)value;
+    P->tile_cache.clear(); P->tiles.erase(k == "ksplit.out" ? "out" : "ffn2");
+    return drop_programs(P, nullptr);
   }
   if (k == "untune") {      // forget the tuned tiles of every shape (tests)
     P->tile_cache.clear(); P->steps_seen.clear(); P->tiles.clear();

@@ -113,7 +113,9 @@ def main(dataset=None, argv=None):
     p = presets.get(dataset)
     steps = a.ddim_steps if a.ddim_steps is not None else (SHIPPED_DDIM_STEPS[dataset] or 100)
     all_styles = a.all_styles or (named and dataset == "vocaset")      # samples/sample_diffusion_vocaset.py:71 loops every one-hot
-    diffusion, ae = pipeline.build_models(dataset, None, a.device, a.stage1_model_path, a.stage2_model_path)
+    # one clip, one condition per sampling call (the reference's bs = 1 loop): the step program's single-clip setting
+    single = a.batch <= 1 and (not all_styles or a.sequential)
+    diffusion, ae = pipeline.build_models(dataset, None, a.device, a.stage1_model_path, a.stage2_model_path, single_clip=single)
     if a.batch > 1 and not all_styles:
         sample_batched(synthetic_loader(p, a.clips, a.seconds), a.device, diffusion, ae, a.out, p, steps, max_batch=a.batch, dataset=dataset)
     else:

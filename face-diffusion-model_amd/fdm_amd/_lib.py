@@ -36,7 +36,8 @@ class GemmArgs(C.Structure):
                 ("stat_out", vp), ("ln_stat_in", vp), ("ln_nparts", ci), ("ln_dim", ci), ("ln_eps", cf),
                 ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci),
                 ("sched_fuse", ci), ("sched", SchedArgs),
-                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll)]
+                ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll),
+                ("ksplit", ci), ("ksplit_stride", ll)]
 
 
 TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP, TILE_80x128, TILE_64x128 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
@@ -66,7 +67,7 @@ class LnArgs(C.Structure):
     _fields_ = [("x", vp), ("M", ci), ("d", ci), ("add_mat", vp), ("add_tab", vp),
                 ("tab_index", vp), ("tab_step", vp), ("gamma", vp), ("beta", vp), ("eps", cf),
                 ("act", ci), ("y_f32", vp), ("y_t", vp), ("dtype", ci), ("gamma2", vp), ("beta2", vp), ("y_t_lo_off", ll),
-                ("add_mat_L", ci), ("add_mat_group", ci), ("add_mat_wrap", ci)]
+                ("add_mat_L", ci), ("add_mat_group", ci), ("add_mat_wrap", ci), ("x_planes", ci), ("x_plane_stride", ll)]
 
 
 # public structs of include/fdm_hip.h -> their mirrors (sizes checked against the loaded library in lib())

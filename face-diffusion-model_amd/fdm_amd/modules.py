@@ -242,6 +242,14 @@ class Wav2Vec2Model(HubertModel):
 
 
 # --------------------------------------------------------------------------------------------------
+# The single-clip setting of the step program: the reference's samplers and demos issue ONE clip per call (bs = 1,
+# samples/sample_diffusion_vocaset.py:51, sample_diffusion_mead.py:67-86) -- 100-250 rows, where the out-proj / FFN2 GEMMs leave
+# most CUs idle behind a 16- / 32-tile dependent k chain.  K slices (2 / 4) reduced by the LayerNorm launch that follows shorten the
+# chain: +10...+19 % at 100-250 rows, -3...-5 % at 800 (profiles/r5_splitk/).  Results move by fp32 rounding (the k sum's association), so it
+# is a property of the PLAN, chosen by the caller, never by the shape: a clip computes the same bits in every batch composition.
+SINGLE_CLIP_PLAN = {"ksplit.out": 2, "ksplit.ffn2": 4}
+
+
 class _FDMBase(ParamTree):
     preset_name = "vocaset"
 
@@ -274,6 +282,7 @@ class _FDMBase(ParamTree):
         self._plan = None
         self._plan_stale = True
         self._prep_key = None
+        self._plan_options = {}                        # fdm_plan_set keys applied to every plan this module builds
         self._hub_key, self._hub = None, None          # _TensorKey of the encoded audio / "injected"
 
     # -- plan management --------------------------------------------------------------------
@@ -281,9 +290,19 @@ class _FDMBase(ParamTree):
         if self._plan is None or self._plan_stale or self._plan.device != torch.device(device):
             sd = {k: v for k, v in self.state_dict().items() if not k.startswith("audio_encoder.")}
             self._plan = DenoiserPlan(self.preset, sd, self._dtype, device)
+            for k, v in self._plan_options.items():
+                self._plan.set(k, v)
             self._plan_stale = False
             self._prep_key = None
         return self._plan
+
+    def set_plan_option(self, key, value):
+        """fdm_plan_set(key, value) on this module's plan, now and after every rebuild (e.g. "ksplit.out" / "ksplit.ffn2": the
+        single-clip setting, SINGLE_CLIP_PLAN below)."""
+        self._plan_options[key] = int(value)
+        if self._plan is not None and not self._plan_stale:
+            self._plan.set(key, int(value))
+            self._prep_key = None
 
     def set_audio_features(self, hub):
         """Inject precomputed HuBERT features [B, N, 1024] (bypasses the audio encoder)."""

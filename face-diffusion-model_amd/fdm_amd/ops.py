@@ -16,8 +16,8 @@ class Split:
     """A split-precision GEMM operand (include/fdm_hip.h, FDM_F16X3 / FDM_BF16X3): planes[0] = hi, planes[1] = lo of a
     [rows, cols] matrix held in one [2, rows, cols] 16-bit tensor.  Slicing rows ([r0:]) keeps the plane distance."""
 
-    def __init__(self, planes, code, row0=0):
-        self.planes, self.code, self.row0 = planes, code, row0
+    def __init__(self, planes, code, row0=0, col0=0):
+        self.planes, self.code, self.row0, self.col0 = planes, code, row0, col0
         self.lo_off = planes[0].numel()
 
     @classmethod
@@ -38,7 +38,7 @@ class Split:
         return self.planes.shape[1:]
 
     def data_ptr(self):
-        return self.planes.data_ptr() + self.row0 * self.planes.shape[2] * self.planes.element_size()
+        return self.planes.data_ptr() + (self.row0 * self.planes.shape[2] + self.col0) * self.planes.element_size()
 
     def numel(self):
         return self.lo_off
@@ -47,6 +47,11 @@ class Split:
         """hi + lo / SCALE as fp32 (tests)."""
         sc = 2048.0 if self.code == F16X3 else 1.0
         return (self.planes[0].float() + self.planes[1].float() / sc)[self.row0:]
+
+
+def cols(t, c0):
+    """The matrix from column c0 on (same row stride: pass lda / ldw = the full width) -- a K range of a GEMM operand."""
+    return Split(t.planes, t.code, t.row0, t.col0 + c0) if isinstance(t, Split) else t[:, c0:]
 
 
 def _p(t):
@@ -88,7 +93,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
          out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
          out_kp=None, kp_col0=0, out_vp=None, vp_col0=0, kv_L=0, kv_Lpad=0, kv_hd=0,
          stat_out=None, ln_stat_in=None, ln_nparts=0, ln_dim=0, ln_eps=1e-5, ln_colsum=None, rln_gamma=None, rln_beta=None,
-         incr_counter=None, incr_table=None, tile=0, sched=None):
+         incr_counter=None, incr_table=None, tile=0, sched=None, ksplit=0, ksplit_stride=0):
     a = GemmArgs()
     a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
     a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
@@ -108,6 +113,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.ln_colsum, a.rln_gamma, a.rln_beta = _p(ln_colsum), _p(rln_gamma), _p(rln_beta)
     a.incr_counter, a.incr_table = _p(incr_counter), _p(incr_table)
     a.tile = tile
+    a.ksplit, a.ksplit_stride = ksplit, ksplit_stride      # S K-slices -> S fp32 partial planes of out_f32 (summed by layernorm(x_planes=S))
     if sched is not None:      # fused scheduler update in the epilogue (resid = x_t, out_f32 = x_{t-1})
         a.sched_fuse, a.sched = 1, sched
     check(lib().fdm_op_gemm(C.byref(a), stream()))
@@ -142,12 +148,13 @@ def attention(Q, Kp, Vp, O, *, B, H, L, hd, ldq, ldo, Lpad, scale, causal=False,
 
 
 def layernorm(x, gamma, beta, M, d, *, add_mat=None, add_tab=None, tab_index=None, tab_step=None, eps=1e-5,
-              act=ACT_NONE, y_f32=None, y_t=None, dtype=F32, gamma2=None, beta2=None):
+              act=ACT_NONE, y_f32=None, y_t=None, dtype=F32, gamma2=None, beta2=None, x_planes=0, x_plane_stride=0):
     a = LnArgs()
     a.x, a.M, a.d, a.add_mat, a.add_tab = _p(x), M, d, _p(add_mat), _p(add_tab)
     a.tab_index, a.tab_step, a.gamma, a.beta, a.eps = _p(tab_index), _p(tab_step), _p(gamma), _p(beta), eps
     a.act, a.y_f32, a.y_t, a.dtype = act, _p(y_f32), _p(y_t), dtype
     a.gamma2, a.beta2, a.y_t_lo_off = _p(gamma2), _p(beta2), _lo(y_t)
+    a.x_planes, a.x_plane_stride = x_planes, x_plane_stride
     check(lib().fdm_op_layernorm(C.byref(a), stream()))
 
 

@@ -41,15 +41,20 @@ def processor_normalize(x, pad_seconds=1.0, sr=16000):
     return x.astype(np.float32)
 
 
-def build_models(preset="vocaset", feature_dim=None, device="cuda:0", stage1=None, stage2=None, dtype=None, cfg_level=None):
+def build_models(preset="vocaset", feature_dim=None, device="cuda:0", stage1=None, stage2=None, dtype=None, cfg_level=None, single_clip=False):
     """(diffusion, autoencoder) with reference-compatible state dicts; checkpoints are loaded when the
     files exist ('model' / 'state_dict' keys as samples/sample_diffusion_vocaset.py:26,91-97), otherwise the
-    seeded random init is kept (there are no checkpoints in this environment)."""
+    seeded random init is kept (there are no checkpoints in this environment).  single_clip: the caller samples one clip per call
+    (the reference's batch size) -- the step program's single-clip setting (modules.SINGLE_CLIP_PLAN)."""
     from dropin_config import vq_args_for
     p = presets.get(preset)
     cls = {"vocaset": FDM, "mead": FDMMead, "biwi": FDMBiwi}[p.name]
     kw = dict(feature_dim=feature_dim or p.d, n_head=(feature_dim or p.d) // p.head_dim, dtype=dtype)
     model = cls(**kw)
+    if single_clip:
+        from .modules import SINGLE_CLIP_PLAN
+        for k, v in SINGLE_CLIP_PLAN.items():
+            model.set_plan_option(k, v)
     ae = VQAutoEncoder(vq_args_for(p.name), dtype=dtype)
     denoise = ClassifierFreeSampleModel(model, cfg_level) if cfg_level else model
     diffusion = GaussianDiffusion(denoise, timesteps=1000, loss_type="l2")

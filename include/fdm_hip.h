@@ -153,6 +153,14 @@ typedef struct fdm_gemm_args {
   /* split operand kinds (dtype FDM_F16X3 / FDM_BF16X3): elements between the hi and lo planes of A, W and out_t */
   long long a_lo_off, w_lo_off, out_t_lo_off;
   long long kv_lo_off;            /* FDM_F16X3 with out_kp / out_vp: elements between the hi and lo planes of the packed buffers */
+  /* --- split K (round 5): ksplit = S > 1 runs S workgroups per output tile (blockIdx.z = slice s); slice s accumulates the
+   * k-tiles [s nk / S, (s + 1) nk / S) in the usual order and stores its fp32 partial tile to out_f32 + s * ksplit_stride
+   * (elements); slice 0 carries bias and residual, the others neither.  The consumer sums the S planes in plane order
+   * (fdm_ln_args.x_planes): no atomics, no extra launch, deterministic.  A workgroup's dependent k chain is 1/S as long and S
+   * chains share a CU.  Results depend on S (the k order changes), never on `tile`.  Needs batch <= 1, act NONE, out_f32 as the
+   * only output, dense vectorisable rows (N % 64 == 0), (K / 64 [16-bit kinds] or K / 32 [fp32]) % S == 0, S <= 4 (8 measured: no further gain); tiles: the
+   * 64x64 family (FDM_TILE_64x64 / _S3 / _S2) and FDM_TILE_32x64_S3. */
+  int ksplit; long long ksplit_stride;
 } fdm_gemm_args;
 #define FDM_TILE_AUTO 0
 #define FDM_TILE_64x64 1
@@ -240,6 +248,9 @@ typedef struct fdm_ln_args {
    * (add_mat_group = S * L, add_mat_L = L, add_mat_wrap = rows per cond/uncond half, 0 = no wrap) over an add_mat of
    * [clips * L, d]; 0 = row m reads add_mat row m */
   int add_mat_L, add_mat_group, add_mat_wrap;
+  /* x given as x_planes (2..4) partial planes, x_plane_stride elements apart (a split-K GEMM's outputs, fdm_gemm_args.ksplit):
+   * the row is ((x[0] + x[1]) + x[2]) + ..., summed in plane order before anything else; 0 / 1 = one plane */
+  int x_planes; long long x_plane_stride;
 } fdm_ln_args;
 int fdm_op_layernorm(const fdm_ln_args* a, void* stream);
 

@@ -27,6 +27,18 @@ TOL = 1e-4
 BF16_FIRST_STEPS_BAR = {"cfg2": 2e-4, "cfg3": 3e-4, "cfg4": 5.2e-4}
 
 
+# UN-ATTENUATED checks at the benched shapes (round 5).  The first steps of a DDPM chain multiply the denoiser's x0_hat by
+# posterior_mean_coef1[999] ~ 1.6e-3 (video_diffusion_pytorch/diffusion_BIWI_encoder_decoder.py:632-639), so the bars above hold
+# an attenuated quantity; the LAST steps (t = 2, 1, 0: coef1 = 0.45, 0.69, 1.0) and a direct denoiser call do not.  bf16 bars =
+# 2x the distance measured on MI355X (printed by the tests with -s); f32 / f16x3 state the contract's 1e-4.
+# measured (round 5): 2.39e-2 / 2.33e-2 / 5.00e-2 / 2.39e-2 / 2.48e-2; f32 1.0e-5 / 9.3e-6 / 1.6e-5 / 8.1e-6 / 7.2e-6; f16x3 6.0e-6 / 5.9e-6 / 9.8e-6 / 6.8e-6 / 5.0e-6
+BF16_UNATTENUATED_BAR = {"cfg2_last": 4.8e-2, "cfg2_denoise": 4.7e-2, "cfg3_last": 0.1, "cfg4_last": 4.8e-2, "cfg5_last": 5.0e-2}
+
+
+def _ubar(dtype, key):
+    return BF16_UNATTENUATED_BAR[key] if dtype == BF16 else TOL
+
+
 def mad(a, b):
     return float((torch.as_tensor(a).double().cpu() - torch.as_tensor(b).double().cpu()).abs().max())
 
@@ -60,6 +72,33 @@ def test_cfg2_first_steps_vs_oracle(dtype):
 
 
 @pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
+def test_cfg2_last_steps_and_direct_denoise_vs_oracle(dtype):
+    """cfg2's program at its benched shape (4 clips x 200 frames), un-attenuated: the LAST three DDPM steps (t = 2, 1, 0, injected
+    noise, seeded x) and one direct denoiser call at t = 500, clips 0 and 3, against the CPU oracle
+    (video_diffusion_pytorch/diffusion_BIWI_encoder_decoder.py:632-656; models/fdm_vocaset.py:56-93)."""
+    preset, B, L = "vocaset", 4, 200
+    w = W.make_fdm_weights(preset)
+    inp = W.synth_inputs(preset, B, L, seed=2)
+    plan = DenoiserPlan(preset, w, dtype, DEV)
+    plan.prepare(inp["hub"], inp["style"], L=L)
+    ts = [2, 1, 0]
+    noise = torch.randn(3, *inp["x"].shape, generator=torch.Generator().manual_seed(0))
+    rec = []
+    plan.sample_ddpm(inp["x"].to(DEV), ts, noise=noise, record=rec)
+    x0 = plan.denoise(inp["x"].to(DEV), 500)
+    worst = worst_d = 0.0
+    for b in (0, 3):
+        den = lambda x, t: FO.fdm_forward(w, preset, inp["hub"][b:b + 1], t, x, inp["style"][b:b + 1], None, folded=True)
+        ref = []
+        FO.p_sample_loop(den, inp["x"][b:b + 1].clone(), noise[:, b:b + 1], ts, record=ref)
+        worst = max(worst, mad(torch.stack(rec)[:, b:b + 1], torch.stack(ref)))
+        worst_d = max(worst_d, mad(x0[b:b + 1], den(inp["x"][b:b + 1], 500)))
+    print(f"[cfg2 dtype {dtype}] last 3 steps (t = 2, 1, 0) vs oracle: max-abs {worst:.3e} (bar {_ubar(dtype, 'cfg2_last'):.1e}); "
+          f"denoise(t = 500) {worst_d:.3e} (bar {_ubar(dtype, 'cfg2_denoise'):.1e})")
+    assert worst < _ubar(dtype, "cfg2_last") and worst_d < _ubar(dtype, "cfg2_denoise")
+
+
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
 def test_cfg3_mead_full_chain_with_guidance(dtype):
     preset, B, L, T = "mead", 4, 300, 1000
     w = W.make_fdm_weights(preset)
@@ -79,6 +118,14 @@ def test_cfg3_mead_full_chain_with_guidance(dtype):
     dist = mad(torch.stack(rec)[:, 1:2], torch.stack(ref))
     print(f"[cfg3 dtype {dtype}] first {k} steps vs oracle: max-abs {dist:.3e} (bar {_bar(dtype, 'cfg3'):.1e})")
     assert dist < _bar(dtype, "cfg3")
+    # un-attenuated: the last three steps (t = 2, 1, 0) of the guided chain from the seeded x, same clip
+    rec = []
+    plan.sample_ddpm(xT, ts[-k:], noise=noise, cfg_scale=2.5, record=rec)
+    ref = []
+    FO.p_sample_loop(den, inp["x"][1:2].clone(), noise[:, 1:2], ts[-k:], record=ref)
+    dist = mad(torch.stack(rec)[:, 1:2], torch.stack(ref))
+    print(f"[cfg3 dtype {dtype}] last {k} steps (t = 2, 1, 0) vs oracle: max-abs {dist:.3e} (bar {_ubar(dtype, 'cfg3_last'):.1e})")
+    assert dist < _ubar(dtype, "cfg3_last")
     # full chain: determinism, finiteness, clip independence under CFG
     a = plan.sample_ddpm(xT, ts, seed=9, cfg_scale=2.5)
     assert a.shape == (B, L * 8, 64) and torch.isfinite(a).all()
@@ -113,6 +160,18 @@ def test_cfg4_biwi_full_ddim_chain(dtype):
         dist = mad(rec[i][3], x)
         print(f"[cfg4 dtype {dtype}] live pair {i} (t = {t}) vs oracle: max-abs {dist:.3e} (bar {_bar(dtype, 'cfg4'):.1e})")
         assert dist < _bar(dtype, "cfg4"), (i, t)
+    # un-attenuated: the last two LIVE pairs of the schedule (t = 8 -> 4 -> 0) from the seeded x, clip 3.  One denoiser call each
+    # through the plan, the oracle's DDIM update applied to both sides' x0_hat
+    x = inp["x"][3].clone()
+    xs = inp["x"].clone()
+    for (t, tn) in pairs[-2:]:
+        x0h = plan.denoise(xs.to(DEV), t).cpu()
+        x0o = _biwi_oracle_clip(w, hub[3].reshape(L, 1536), t, x, inp["style"][3])
+        dist = mad(x0h[3], x0o)
+        print(f"[cfg4 dtype {dtype}] last live pairs, denoise(t = {t}) vs oracle: max-abs {dist:.3e} (bar {_ubar(dtype, 'cfg4_last'):.1e})")
+        assert dist < _ubar(dtype, "cfg4_last"), t
+        x = FO.ddim_step(buf, x0o, x, t, tn)
+        xs[3] = x
     # properties over the whole 249-call chain
     assert torch.equal(a, plan.sample_ddim(xT, steps)), "not deterministic"
     assert torch.equal(a, plan.sample_ddim(xT, steps, graph_steps=1)), "steps per graph launch changed the result"
@@ -159,6 +218,16 @@ def test_cfg5_vocaset_end_to_end_composed(mode):
         worst = max(worst, mad(torch.stack(rec)[:, b:b + 1], torch.stack(ref)))
     print(f"[cfg5 {mode}] first {k} steps vs oracle: max-abs {worst:.3e} (bar {bar:.1e})")
     assert worst < bar, mode
+    # un-attenuated: the last three steps (t = 2, 1, 0) at L = 498 from the seeded x, clip 0
+    rec = []
+    plan.sample_ddpm(xT, ts[-3:], noise=noise[:3], record=rec)
+    den = lambda x, t: FO.fdm_forward(w, preset, hub_c[0:1], t, x, inp["style"][0:1], None, folded=True)
+    ref = []
+    FO.p_sample_loop(den, inp["x"][0:1].clone(), noise[:3, 0:1], ts[-3:], record=ref)
+    last = mad(torch.stack(rec)[:, 0:1], torch.stack(ref))
+    ubar = _ubar(dt, "cfg5_last")
+    print(f"[cfg5 {mode}] last 3 steps (t = 2, 1, 0) vs oracle: max-abs {last:.3e} (bar {ubar:.1e})")
+    assert last < ubar, mode
 
     def run(clips, clip0):
         plan.prepare(hub[clips], inp["style"][clips], L=L)

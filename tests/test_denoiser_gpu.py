@@ -131,6 +131,44 @@ def test_batched_clips_equal_independent_b1_calls(preset, dtype):
         assert torch.equal(one[0], out[b]), "per-clip result depends on the batch"
 
 
+@pytest.mark.parametrize("preset,dtype,So,Sf", [("vocaset", F32, 2, 4), ("vocaset", F16X3, 4, 4), ("mead", F16X3, 2, 4), ("vocaset", BF16, 2, 4)])
+def test_split_k_plan_property_keeps_parity_and_batch_independence(golden, preset, dtype, So, Sf):
+    """fdm_plan_set "ksplit.out" / "ksplit.ffn2" (the single-clip callers' setting: K slices of the out-proj / FFN2 GEMMs, summed by
+    the LayerNorm launch that follows): same bars against the reference goldens, the graph == eager launches, and -- S being a
+    property of the plan, not of the shape -- a clip still computes the same bits in every batch composition."""
+    w = W.make_fdm_weights(preset)
+    plan = DenoiserPlan(preset, w, dtype, DEV)
+    plan.set("ksplit.out", So); plan.set("ksplit.ffn2", Sf)
+    assert plan.get("ksplit.out") == So and plan.get("ksplit.ffn2") == Sf
+    g = golden(f"fdm_step_{preset}")
+    worst = 0.0
+    for (L, t) in g["cases"].tolist():
+        inp = W.synth_inputs(preset, 1, L, seed=100 + L)
+        plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+        worst = max(worst, mad(plan.denoise(inp["x"].to(DEV), t)[0], g[f"x0_L{L}_t{t}"]))
+    print(f"[{preset} dtype {dtype} ksplit {So}/{Sf}] single steps vs reference goldens: max-abs {worst:.3e}")
+    assert worst < (TOLBF if dtype == BF16 else TOL32)
+    gc = golden(f"chains_{preset}")
+    L = int(gc["L"])
+    inp = W.synth_inputs(preset, 1, L, seed=7)
+    plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+    noise = torch.from_numpy(gc["ddpm_lo_noise"])
+    a = plan.sample_ddpm(inp["x"].to(DEV), gc["ddpm_lo_t"].tolist(), noise=noise, use_graph=True)
+    b = plan.sample_ddpm(inp["x"].to(DEV), gc["ddpm_lo_t"].tolist(), noise=noise, use_graph=False)
+    assert torch.equal(a, b)
+    assert mad(a, gc["ddpm_lo_steps"][-1]) < (0.15 if dtype == BF16 else TOL32)
+    B, L, t = 3, 37, 640
+    inp = W.synth_inputs(preset, B, L, seed=21)
+    plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+    out = plan.denoise(inp["x"].to(DEV), t).cpu()
+    plan.prepare(inp["hub"][2:3], inp["style"][2:3], None if "emo" not in inp else inp["emo"][2:3], L=L)
+    assert torch.equal(plan.denoise(inp["x"][2:3].to(DEV), t).cpu()[0], out[2]), "per-clip result depends on the batch"
+    plan.tune()          # the tuner's candidates at a K-sliced site are the 64-column tiles; tiles never change results
+    assert torch.equal(plan.denoise(inp["x"][2:3].to(DEV), t).cpu()[0], out[2])
+    with pytest.raises(Exception):
+        plan.set("ksplit.out", 3)
+
+
 def test_ddpm_chain_with_device_noise_is_deterministic_and_shardable():
     """Philox noise is keyed by (seed, global clip index, step): a rank holding clips [1, 3) of a
     3-clip job reproduces those clips bit for bit."""

@@ -34,6 +34,65 @@ def act_ref(x, act):
     return x
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
+@pytest.mark.parametrize("M,N,K,S,tile", [(100, 1024, 1024, 4, 9), (249, 512, 1024, 2, 1), (800, 1024, 2048, 4, 8), (100, 1024, 2048, 4, 9),
+                                          (37, 256, 512, 2, 6), (800, 1024, 1024, 2, 0)])
+def test_gemm_split_k_planes_summed_by_layernorm(dtype, M, N, K, S, tile):
+    """fdm_gemm_args.ksplit: S K-slices write S fp32 partial planes (slice 0 with bias + residual), fdm_ln_args.x_planes sums them
+    in plane order.  (a) the planes add up to the unsplit product (fp32-class: only the association of the k sum differs);
+    (b) every slice equals an ordinary GEMM over its own K range, bit for bit; (c) LayerNorm over the planes == LayerNorm of their
+    fixed-order sum, bit for bit; (d) the tile changes nothing."""
+    g = torch.Generator().manual_seed(M + N + K + S)
+    A32 = torch.randn(M, K, generator=g)
+    W32 = torch.randn(N, K, generator=g) / math.sqrt(K)
+    A, Wt = ops.to_operand(A32.to(DEV), dtype), ops.to_operand(W32.to(DEV), dtype)
+    bias = torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    planes = torch.full((S, M, N), float("nan"), device=DEV)
+    ops.gemm(A, Wt, M, N, K, bias=bias, resid=resid, out_f32=planes, tile=tile, ksplit=S, ksplit_stride=M * N)
+    one = torch.zeros(M, N, device=DEV)
+    ops.gemm(A, Wt, M, N, K, bias=bias, resid=resid, out_f32=one)
+    torch.cuda.synchronize()
+    assert torch.isfinite(planes).all()
+    acc = planes[0].clone()
+    for s_ in range(1, S):
+        acc += planes[s_]
+    assert rel(acc, one) < 2e-6      # same operands in every kind: only the association of the k sum differs
+    # (b) slice s == the GEMM over columns [s K / S, (s + 1) K / S) of both operands (lda = ldw = K, pointers advanced)
+    Ks = K // S
+    for s_ in (0, S - 1):
+        ref = torch.zeros(M, N, device=DEV)
+        ops.gemm(ops.cols(A, s_ * Ks), ops.cols(Wt, s_ * Ks), M, N, Ks, lda=K, ldw=K, bias=bias if s_ == 0 else None, resid=resid if s_ == 0 else None, out_f32=ref)
+        torch.cuda.synchronize()
+        assert torch.equal(ref, planes[s_]), s_
+    # (c) LayerNorm over the planes
+    if N in (256, 512, 768, 1024):
+        gam, bet = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+        y1, y2 = torch.zeros(M, N, device=DEV), torch.zeros(M, N, device=DEV)
+        ops.layernorm(planes, gam, bet, M, N, y_f32=y1, x_planes=S, x_plane_stride=M * N)
+        ops.layernorm(acc, gam, bet, M, N, y_f32=y2)
+        torch.cuda.synchronize()
+        assert torch.equal(y1, y2)
+    # (d) another tile, same bits
+    p2 = torch.zeros(S, M, N, device=DEV)
+    ops.gemm(A, Wt, M, N, K, bias=bias, resid=resid, out_f32=p2, tile=(6 if tile != 6 else 1), ksplit=S, ksplit_stride=M * N)
+    torch.cuda.synchronize()
+    assert torch.equal(p2, planes)
+
+
+def test_gemm_split_k_argument_checks():
+    from fdm_amd._lib import FdmError
+    A = torch.zeros(64, 1024, device=DEV, dtype=torch.bfloat16); Wt = torch.zeros(128, 1024, device=DEV, dtype=torch.bfloat16)
+    out = torch.zeros(4, 64, 128, device=DEV)
+    for kw in (dict(ksplit=3), dict(ksplit=5), dict(ksplit=2, act=ACT_RELU), dict(ksplit=2, tile=3), dict(ksplit=2, out_t=torch.zeros(64, 128, device=DEV, dtype=torch.bfloat16)),
+               dict(ksplit=2, ksplit_stride=100)):
+        kw.setdefault("ksplit_stride", 64 * 128)
+        with pytest.raises(FdmError):
+            ops.gemm(A, Wt, 64, 128, 1024, out_f32=out, **kw)
+    with pytest.raises(FdmError):
+        ops.layernorm(out, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), 64, 256, y_f32=out, x_planes=2, x_plane_stride=8)
+
+
 @pytest.mark.parametrize("dtype", [F32, BF16])
 @pytest.mark.parametrize("M,N,K,act", [(7, 256, 256, ACT_MISH), (100, 1024, 1024, ACT_NONE), (800, 3072, 1024, ACT_RELU),
                                        (33, 15069, 1024, ACT_NONE), (257, 192, 2048, ACT_GELU_ERF),
