@@ -410,12 +410,17 @@ int fdm_hubert_forward(fdm_audio_encoder* E, const float* wav, int B, int n, int
   const size_t ee = fsplit ? 2 : es;                                     // bytes per element of a plane
   FCK(fdm_op_group_pad(ht, E->xg, B, N, D, POS_G, POS_K / 2, dt, stream));
   if (fsplit) FCK(fdm_op_group_pad((const char*)ht + (size_t)M * D * 2, (char*)E->xg + (size_t)xg_plane * 2, B, N, D, POS_G, POS_K / 2, dt, stream));
-  for (int b = 0; b < B; ++b) {
-    fdm_gemm_args pg = gemm_args(dt, (const char*)E->xg + (size_t)b * (N + POS_K) * dg * ee, E->pc_w.p, N, dg, POS_K * dg);
+  {
+    // ONE launch for all clips (round 5; one launch per clip before): z = (clip, group), the weights of a group shared by the clips
+    // and by the row tiles, workgroups dealt so that every XCD works on two groups only -- its L2 streams 1 / 8 of the 16.8 MB
+    // weight once (fdm_gemm_args.batch2).  Per clip the launch fetched 133 MB for 18 MB of operands (profiles/r4_pmc_hubert_bf16_B4).
+    (void)ee;
+    fdm_gemm_args pg = gemm_args(dt, E->xg, E->pc_w.p, N, dg, POS_K * dg);
     pg.lda = dg; pg.batch = POS_G; pg.a_batch_stride = (long long)B * (N + POS_K) * dg; pg.w_batch_stride = (long long)dg * POS_K * dg;
+    pg.batch2 = B; pg.a_batch_stride2 = (long long)(N + POS_K) * dg; pg.out_batch_stride2 = (long long)N * D;
     pg.a_lo_off = fsplit ? xg_plane : 0; pg.w_lo_off = E->pc_w.lo;
     pg.bias = E->pc_b; pg.bias_batch_stride = dg; pg.act = FDM_ACT_GELU_ERF;
-    pg.resid = E->h + (size_t)b * N * D; pg.ldr = D; pg.out_f32 = E->h2 + (size_t)b * N * D; pg.ldo_f32 = D; pg.out_batch_stride = dg;
+    pg.resid = E->h; pg.ldr = D; pg.out_f32 = E->h2; pg.ldo_f32 = D; pg.out_batch_stride = dg;
     FCK(fdm_op_gemm(&pg, stream));
   }
   float* h = E->h2;

@@ -162,6 +162,16 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
     if (tl != 0 && tl != FDM_TILE_64x64 && tl != FDM_TILE_64x64_S3 && tl != FDM_TILE_64x64_S2 && tl != FDM_TILE_32x64_S3)
       return fail(FDM_ERR_ARG, "gemm: ksplit runs on the 64-column tiles (FDM_TILE_64x64, _S3, _S2, FDM_TILE_32x64_S3), not tile %d", tl);
   }
+  if (a->batch2 < 0) return fail(FDM_ERR_ARG, "gemm: negative batch2");
+  if (a->batch2 >= 1) {
+    const int tl = a->tile & ~FDM_TILE_GENERAL;
+    if (a->dtype == FDM_BF16X3) return fail(FDM_ERR_ARG, "gemm: batch2 is not offered for the bf16x3 comparison kind");
+    if (a->ksplit > 1 || a->out_kp || a->out_vp || a->stat_out || a->ln_stat_in || a->sched_fuse || a->resid_row_mod || a->incr_counter)
+      return fail(FDM_ERR_ARG, "gemm: batch2 cannot be combined with ksplit, packed K/V, LayerNorm folds, the fused scheduler or resid_row_mod");
+    if (a->a_batch_stride2 % epc) return fail(FDM_ERR_ARG, "gemm: a_batch_stride2 needs 16-byte alignment");
+    if (tl != 0 && tl != FDM_TILE_64x64 && tl != FDM_TILE_64x64_S3 && tl != FDM_TILE_64x64_S2 && tl != FDM_TILE_128x64 && tl != FDM_TILE_128x64_S3)
+      return fail(FDM_ERR_ARG, "gemm: batch2 runs on the 64-column tiles (FDM_TILE_64x64, _S3, _S2, FDM_TILE_128x64, _S3), not tile %d", tl);
+  }
   fdm_gemm_args c = *a;
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
 }

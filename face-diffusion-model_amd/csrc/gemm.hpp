@@ -131,20 +131,30 @@ __host__ __device__ inline bool gemm_act_is_heavy(int act) { return act == ACT_M
 // instruction fetch -- is not compiled in.
 // SPEC further says what the launch can need: GEMM_KV = packed K / V outputs, GEMM_FOLD = the LayerNorm-folding producer /
 // consumer forms; a lean kernel without either is bias + activation + residual + stores (a few hundred instructions).
-constexpr int GEMM_LEAN = 1, GEMM_KV = 2, GEMM_FOLD = 4, GEMM_KSPLIT = 8;
+constexpr int GEMM_LEAN = 1, GEMM_KV = 2, GEMM_FOLD = 4, GEMM_KSPLIT = 8, GEMM_B2 = 16;
 // GEMM_KSPLIT (with GEMM_LEAN): blockIdx.z is a K slice, not a batch index -- slice s runs k-tiles [s nk / S, (s + 1) nk / S) and
 // stores its fp32 partial tile to plane s of out_f32; slice 0 alone adds bias and residual (fdm_gemm_args.ksplit).  The
 // epilogue sees the slice's view of the arguments:
-template <bool KSP> struct KSliceArgs;
-template <> struct KSliceArgs<false> {
+// GEMM_B2: a second batch level (fdm_gemm_args.batch2): the epilogue's outputs and residual advance by out_batch_stride2 per c.
+template <int MODE> struct KSliceArgs;      // MODE: 0 plain, 1 K slice, 2 second batch level
+template <> struct KSliceArgs<0> {
   const fdm_gemm_args& a;
-  __device__ __forceinline__ KSliceArgs(const fdm_gemm_args& p, int) : a(p) {}
+  __device__ __forceinline__ KSliceArgs(const fdm_gemm_args& p, int, int) : a(p) {}
 };
-template <> struct KSliceArgs<true> {
+template <> struct KSliceArgs<1> {
   fdm_gemm_args a;
-  __device__ __forceinline__ KSliceArgs(const fdm_gemm_args& p, int slice) : a(p) {
+  __device__ __forceinline__ KSliceArgs(const fdm_gemm_args& p, int slice, int) : a(p) {
     a.out_f32 = p.out_f32 + (size_t)slice * p.ksplit_stride;
     if (slice > 0) { a.bias = nullptr; a.resid = nullptr; }
+  }
+};
+template <> struct KSliceArgs<2> {
+  fdm_gemm_args a;
+  __device__ __forceinline__ KSliceArgs(const fdm_gemm_args& p, int c, int out_t_elem_bytes) : a(p) {
+    const size_t off = (size_t)c * p.out_batch_stride2;
+    if (p.out_f32) a.out_f32 = p.out_f32 + off;
+    if (p.resid) a.resid = p.resid + off;
+    if (p.out_t) a.out_t = (char*)p.out_t + off * out_t_elem_bytes;
   }
 };
 template <typename T, int BM, int BN, int WM = 2, int WN = 2, bool HEAVY = true, bool SCHED = false, int SPEC = 0>
@@ -449,9 +459,29 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int g = lane >> 4, r16 = lane & 15;
-  constexpr bool KSP = (SPEC & GEMM_KSPLIT) != 0;
-  const int z = KSP ? 0 : blockIdx.z;            // batch index (a K-sliced launch is not batched)
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  constexpr bool KSP = (SPEC & GEMM_KSPLIT) != 0, B2 = (SPEC & GEMM_B2) != 0;
+  int z = KSP ? 0 : blockIdx.z;                  // batch index (a K-sliced launch is not batched)
+  int by = blockIdx.y, bx = blockIdx.x, c2 = 0;
+  if constexpr (B2) {
+    // second batch level: grid z = batch2 * batch.  Workgroups are dispatched in linear-id order round-robin over the 8 XCDs, so
+    // id % 8 names the L2 a workgroup runs behind: deal the ids so that XCD x works on groups [x G / 8, (x + 1) G / 8) only,
+    // group-major (all clips and row tiles of one group back to back): each L2 streams its share of W exactly once.
+    const int nx = gridDim.x, ny = gridDim.y, G = p.batch, C = p.batch2;
+    const int id = (blockIdx.z * ny + blockIdx.y) * nx + blockIdx.x;
+    int g_, r;
+    if (G % 8 == 0) {
+      const int per_g = ny * nx * C, slot = id >> 3;
+      const int gl = slot / per_g;
+      g_ = (id & 7) * (G / 8) + gl; r = slot - gl * per_g;
+    } else {
+      const int per_g = ny * nx * C;
+      g_ = id / per_g; r = id - g_ * per_g;
+    }
+    z = g_; c2 = r / (ny * nx);
+    const int r2 = r - c2 * ny * nx;
+    by = r2 / nx; bx = r2 - by * nx;
+  }
+  const int m0 = by * BM, n0 = bx * BN;
   const int M = p.M, N = p.N;
   constexpr int EPC = 16 / (int)sizeof(E);
   int nk = p.K / (KCH * EPC);
@@ -462,7 +492,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
     A += (size_t)blockIdx.z * nk * (KCH * EPC);
     W += (size_t)blockIdx.z * nk * (KCH * EPC);
   }
-  const KSliceArgs<KSP> ksa(p, blockIdx.z);
+  if constexpr (B2) A += (size_t)c2 * p.a_batch_stride2;
+  const KSliceArgs<KSP ? 1 : (B2 ? 2 : 0)> ksa(p, KSP ? (int)blockIdx.z : c2, (int)sizeof(E));
   const fdm_gemm_args& pe = ksa.a;               // what the epilogue reads (bias, residual, outputs)
   const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);   // bytes hi plane -> lo plane
 
@@ -891,7 +922,7 @@ static hipError_t gemm_pp_launch_h(const fdm_gemm_args& a, hipStream_t s) {
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false, int SPEC = 0>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
-  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, (SPEC & GEMM_KSPLIT) ? a.ksplit : (a.batch > 0 ? a.batch : 1));
+  dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, (SPEC & GEMM_KSPLIT) ? a.ksplit : (a.batch > 0 ? a.batch : 1) * ((SPEC & GEMM_B2) ? a.batch2 : 1));
   constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
   static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
   static bool once = [] {
@@ -927,6 +958,15 @@ static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
     if constexpr (BN == 64 && (BM == 64 || BM == 32)) {
       if (!gemm_all_tiles_lean<T, BM, BN>(a)) return hipErrorInvalidValue;
       return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KSPLIT>(a, s);
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
+  if (a.batch2 >= 1) {       // second batch level (validated by fdm_op_gemm): two kernels per tile, both with every activation compiled in
+    if constexpr (BN == 64 && (BM == 64 || BM == 128)) {
+      if (!no_lean && gemm_all_tiles_lean<T, BM, BN>(a) && a.out_batch_stride2 % 4 == 0)
+        return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_LEAN | GEMM_B2>(a, s);
+      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_B2>(a, s);
     } else {
       return hipErrorInvalidValue;
     }
@@ -984,6 +1024,10 @@ static bool gemm_one_round_80(const fdm_gemm_args& a) {
 // elem_bytes: 4 (fp32) or 2; split: the two-plane kinds (a ring stage is twice as large there, so their tile set is the part
 // of the one-plane set whose ring fits 160 KB of LDS)
 static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool split) {
+  if (a.batch2 >= 1) {       // grouped conv over clips: 128-row tiles once they fill the chip (one round of 256: 4 row tiles x 16 groups x 4 clips), else 64
+    const long long t128b = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * (a.batch > 0 ? a.batch : 1) * a.batch2;
+    return t128b >= 192 ? (split ? FDM_TILE_128x64_S3 : FDM_TILE_128x64) : FDM_TILE_64x64;
+  }
   const long long batch = a.batch > 0 ? a.batch : 1;
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
   const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;

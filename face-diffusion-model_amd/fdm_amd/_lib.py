@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
                 ("ln_colsum", vp), ("rln_gamma", vp), ("rln_beta", vp), ("incr_counter", vp), ("incr_table", vp), ("tile", ci),
                 ("sched_fuse", ci), ("sched", SchedArgs),
                 ("a_lo_off", ll), ("w_lo_off", ll), ("out_t_lo_off", ll), ("kv_lo_off", ll),
-                ("ksplit", ci), ("ksplit_stride", ll)]
+                ("ksplit", ci), ("ksplit_stride", ll), ("batch2", ci), ("a_batch_stride2", ll), ("out_batch_stride2", ll)]
 
 
 TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP, TILE_80x128, TILE_64x128 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12

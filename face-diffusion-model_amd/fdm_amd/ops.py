@@ -93,7 +93,8 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
          out_f32=None, ldo_f32=None, out_t=None, ldo_t=None, batch=1, a_bs=0, w_bs=0, bias_bs=0, out_bs=0,
          out_kp=None, kp_col0=0, out_vp=None, vp_col0=0, kv_L=0, kv_Lpad=0, kv_hd=0,
          stat_out=None, ln_stat_in=None, ln_nparts=0, ln_dim=0, ln_eps=1e-5, ln_colsum=None, rln_gamma=None, rln_beta=None,
-         incr_counter=None, incr_table=None, tile=0, sched=None, ksplit=0, ksplit_stride=0):
+         incr_counter=None, incr_table=None, tile=0, sched=None, ksplit=0, ksplit_stride=0,
+         batch2=0, a_bs2=0, out_bs2=0):
     a = GemmArgs()
     a.A, a.lda, a.a_batch_stride = _p(A), lda if lda is not None else K, a_bs
     a.W, a.ldw, a.w_batch_stride = _p(W), ldw if ldw is not None else K, w_bs
@@ -113,6 +114,7 @@ def gemm(A, W, M, N, K, *, lda=None, ldw=None, bias=None, act=ACT_NONE, resid=No
     a.ln_colsum, a.rln_gamma, a.rln_beta = _p(ln_colsum), _p(rln_gamma), _p(rln_beta)
     a.incr_counter, a.incr_table = _p(incr_counter), _p(incr_table)
     a.tile = tile
+    a.batch2, a.a_batch_stride2, a.out_batch_stride2 = batch2, a_bs2, out_bs2      # second batch level: W / bias shared (grouped conv over clips)
     a.ksplit, a.ksplit_stride = ksplit, ksplit_stride      # S K-slices -> S fp32 partial planes of out_f32 (summed by layernorm(x_planes=S))
     if sched is not None:      # fused scheduler update in the epilogue (resid = x_t, out_f32 = x_{t-1})
         a.sched_fuse, a.sched = 1, sched

@@ -161,6 +161,13 @@ typedef struct fdm_gemm_args {
    * only output, dense vectorisable rows (N % 64 == 0), (K / 64 [16-bit kinds] or K / 32 [fp32]) % S == 0, S <= 4 (8 measured: no further gain); tiles: the
    * 64x64 family (FDM_TILE_64x64 / _S3 / _S2) and FDM_TILE_32x64_S3. */
   int ksplit; long long ksplit_stride;
+  /* --- second batch level (round 5): batch2 = C >= 1 runs C x batch problems in one launch, z = (c, g): A advances by
+   * a_batch_stride per g and by a_batch_stride2 per c, outputs and resid by out_batch_stride (a column offset) per g and by
+   * out_batch_stride2 (elements: a row offset) per c; W and bias depend on g alone.  This is a grouped Conv1d over C clips
+   * (HuBERT's positional conv: g = channel group, c = clip).  When batch % 8 == 0 the workgroups are dealt so that XCD x serves
+   * the groups [x batch / 8, (x + 1) batch / 8) only, group-major: each L2 streams its 1 / 8 of W once for all clips and row
+   * tiles.  Tiles: FDM_TILE_64x64 / _S3 and FDM_TILE_128x64 / _S3; no ksplit, no LayerNorm folds, no packed K / V, no fused scheduler. */
+  int batch2; long long a_batch_stride2, out_batch_stride2;
 } fdm_gemm_args;
 #define FDM_TILE_AUTO 0
 #define FDM_TILE_64x64 1

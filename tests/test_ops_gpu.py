@@ -80,6 +80,41 @@ def test_gemm_split_k_planes_summed_by_layernorm(dtype, M, N, K, S, tile):
     assert torch.equal(p2, planes)
 
 
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
+@pytest.mark.parametrize("C,G,T,dg,KW,tile", [(4, 16, 123, 64, 16, 0), (3, 16, 70, 48, 8, 1), (2, 4, 200, 64, 8, 2), (1, 16, 50, 64, 8, 0)])
+def test_gemm_second_batch_level_equals_per_clip_launches(dtype, C, G, T, dg, KW, tile):
+    """fdm_gemm_args.batch2: a grouped Conv1d (HuBERT's positional conv: models/hubert.py:110-137 over transformers'
+    HubertPositionalConvEmbedding) for all clips in ONE launch -- z = (clip, group), workgroups dealt so that an XCD serves its
+    own groups only -- against one launch per clip: bit-identical, in the lean and the edge-handling kernel (dg = 48), for a group
+    count that does (16) and does not (4) divide over the 8 XCDs, and == a torch grouped conv."""
+    g = torch.Generator().manual_seed(C * 100 + T)
+    D = G * dg
+    x = torch.randn(C, T + KW, D, generator=g)                                  # padded channels-last signal
+    w = torch.randn(G, dg, KW * dg, generator=g) / math.sqrt(KW * dg)            # [group][out][tap * in]
+    bias = torch.randn(D, generator=g).to(DEV)
+    resid = torch.randn(C * T, D, generator=g).to(DEV)
+    xg32 = x.reshape(C, T + KW, G, dg).permute(2, 0, 1, 3).contiguous().to(DEV)   # [G, C, T + KW, dg]
+    xg = ops.to_operand(xg32.reshape(G * C * (T + KW), dg), dtype)
+    wt = ops.to_operand(w.reshape(G * dg, KW * dg).to(DEV), dtype)
+    kw = dict(lda=dg, batch=G, a_bs=C * (T + KW) * dg, w_bs=dg * KW * dg, bias=bias, bias_bs=dg, act=ACT_GELU_ERF, ldr=D, ldo_f32=D, out_bs=dg)
+    one = torch.zeros(C * T, D, device=DEV)
+    ops.gemm(xg, wt, T, dg, KW * dg, resid=resid, out_f32=one, batch2=C, a_bs2=(T + KW) * dg, out_bs2=T * D, tile=tile, **kw)
+    per = torch.zeros(C * T, D, device=DEV)
+    for c in range(C):
+        ops.gemm(xg[c * (T + KW):], wt, T, dg, KW * dg, resid=resid[c * T:], out_f32=per[c * T:], **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(one, per)
+    # reference: conv as written (weights back to [out, in, tap] per group; operands as the kernel sees them)
+    xr = xg.float().reshape(G, C, T + KW, dg) if ops.is_split(dtype) else xg.float().reshape(G, C, T + KW, dg)
+    wr = wt.float().reshape(G, dg, KW, dg)
+    ref = torch.zeros(C, T, D, dtype=torch.float64)
+    for gi in range(G):
+        win = xr[gi].double().cpu().unfold(1, KW, 1)[:, :T]                     # [C, T, dg_in, KW]
+        ref[:, :, gi * dg:(gi + 1) * dg] = torch.einsum("ctik,oki->cto", win, wr[gi].double().cpu())
+    ref = F.gelu(ref + bias.double().cpu()) + resid.double().cpu().reshape(C, T, D)
+    assert rel(one.reshape(C, T, D), ref) < (2e-5 if dtype != BF16 else 2e-5)
+
+
 def test_gemm_split_k_argument_checks():
     from fdm_amd._lib import FdmError
     A = torch.zeros(64, 1024, device=DEV, dtype=torch.bfloat16); Wt = torch.zeros(128, 1024, device=DEV, dtype=torch.bfloat16)
