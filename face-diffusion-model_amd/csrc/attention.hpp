@@ -310,9 +310,8 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
         for (int w = 0; w < 4; ++w) v += *(const f32x4*)&part_o[w][q][e0 + j] * sw[w];
         v *= inv;
         if constexpr (std::is_same<T, float>::value) {
-          // fp32 attention feeding a split-operand GEMM (BF16X3 step programs): O is written as the plane pair
+          // fp32 attention feeding a split-operand GEMM: O is written as the plane pair
           if (p.o_split == FDM_F16X3) store_opnd4<f16x3_t>((f16*)p.O + oo + j, p.o_lo_off, v);
-          else if (p.o_split == FDM_BF16X3) store_opnd4<bf16x3_t>((bf16*)p.O + oo + j, p.o_lo_off, v);
           else *(f32x4*)((float*)p.O + oo + j) = v;
         } else {
           store_opnd4<T>((E*)p.O + oo + j, p.o_lo_off, v);

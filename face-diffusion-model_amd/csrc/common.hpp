@@ -52,15 +52,12 @@ template <typename E> __device__ __forceinline__ void mma16(f32x4& acc, const u3
 // hi.hi + (hi.lo + lo.hi) / SCALE on the 16-bit MFMA (three passes; the lo.lo term is below the representation error).
 //   f16x3_t : fp16 planes, 11 significant bits each -> 22 bits per operand, fp32-class results (SCALE = 2^11 keeps the
 //             residual plane in fp16's normal range; the two small products are summed in their own accumulator)
-//   bf16x3_t: bf16 planes, 8 bits each -> 16 bits per operand (kept for comparison: ~5e-5 per denoiser call)
 // E = element type in memory, NP = planes, KV = operand kind of the packed K / V outputs of a QKV projection in that mode
-// (f16x3 feeds the split attention kernel plane pairs; bf16x3, the comparison mode, feeds the fp32 attention kernel).
+// (f16x3 feeds the split attention kernel plane pairs).
 // ---------------------------------------------------------------------------------------------------
 struct f16x3_t {};
-struct bf16x3_t {};
 template <typename T> struct Opnd { using E = T; using KV = T; static constexpr int NP = 1; static constexpr float SCALE = 1.f; };
 template <> struct Opnd<f16x3_t> { using E = f16; using KV = f16x3_t; static constexpr int NP = 2; static constexpr float SCALE = 2048.f; };
-template <> struct Opnd<bf16x3_t> { using E = bf16; using KV = float; static constexpr int NP = 2; static constexpr float SCALE = 1.f; };
 
 // Store 4 consecutive fp32 values v as operand kind T at dst (split kinds: hi plane at dst, lo plane at dst + lo_off).
 template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, long long lo_off, const f32x4& v) {
@@ -120,8 +117,9 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-// GELU(erf) for the bf16 (throughput) kind: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside the 2^-9 rounding of the
-// bf16 value it feeds) on the hardware exp -- a dozen instructions instead of libm erff's ~50 per element (HuBERT's FFN1 epilogue,
+// GELU(erf) for the bf16 (throughput) kind: erf by Abramowitz-Stegun 7.1.26 (ABSOLUTE error <= 1.5e-7 on erf: far inside the 2^-9
+// rounding of the bf16 value it feeds wherever |GELU| > 1e-4; on the negative tail, v < -4, where |GELU(v)| itself is below 1e-4, the
+// relative error is of the order of bf16's own rounding -- absolute 1e-7 there) on the hardware exp -- a dozen instructions instead of libm erff's ~50 per element (HuBERT's FFN1 epilogue,
 // the conv LayerNorm + GELU kernels).  The fp32 and split (parity) kinds keep erff.
 __device__ __forceinline__ float gelu_erf_fast(float v) {
   const float x = fabsf(v) * 0.70710678118654752440f;

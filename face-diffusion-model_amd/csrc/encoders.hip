@@ -287,7 +287,8 @@ int enc_reserve(fdm_audio_encoder* E, int B, int n) {
   conv_lengths(n, T);
   const size_t es = esize(E->front_dtype()), esl = esize(E->dtype), D = E->D;
   const size_t r0 = (size_t)B * T[0], N = (size_t)T[6] + 2, M = (size_t)B * N;
-  FCK(E->ws.alloc_t(&E->x32, r0 * CD)); FCK(E->ws.alloc_t(&E->y32, (size_t)B * T[1] * CD));
+  if (!E->conv_layer_norm) FCK(E->ws.alloc_t(&E->x32, r0 * CD));      // conv 0's fp32 output: only the GroupNorm front (wav2vec2-base) materialises it
+  FCK(E->ws.alloc_t(&E->y32, (size_t)B * T[1] * CD));
   FCK(E->ws.alloc(&E->xa, r0 * CD * es)); FCK(E->ws.alloc(&E->xb, (size_t)B * T[1] * CD * es));
   FCK(E->ws.alloc_t(&E->g6, M * CD)); FCK(E->ws.alloc_t(&E->gi, M * CD)); FCK(E->ws.alloc(&E->ft, M * CD * es));
   FCK(E->ws.alloc_t(&E->h, M * D)); FCK(E->ws.alloc_t(&E->h2, M * D)); FCK(E->ws.alloc_t(&E->hb, M * D)); FCK(E->ws.alloc_t(&E->x1, M * D));
@@ -314,7 +315,7 @@ int fdm_hubert_create(int kind, int n_layers, int dtype, fdm_audio_encoder** out
   if (!out) return fail(FDM_ERR_ARG, "hubert_create: null out");
   if (kind != 0 && kind != 1) return fail(FDM_ERR_ARG, "hubert_create: kind %d (0 = HuBERT-large, 1 = wav2vec2-base)", kind);
   if (dtype != FDM_F32 && dtype != FDM_BF16 && dtype != FDM_F16X3)
-    return fail(FDM_ERR_ARG, "hubert_create: dtype %d (fp32, bf16, or FDM_F16X3 = split-fp16 transformer layers behind an fp32 front)", dtype);
+    return fail(FDM_ERR_ARG, "hubert_create: dtype %d (fp32, bf16, or FDM_F16X3 = split-fp16 operands in the conv front and the transformer layers)", dtype);
   fdm_audio_encoder* E = new (std::nothrow) fdm_audio_encoder();
   if (!E) return fail(FDM_ERR_STATE, "hubert_create: out of memory");
   E->kind = kind; E->dtype = dtype;

@@ -8,7 +8,6 @@
 #include <cstring>
 #include <functional>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/fdm_hip.h"
@@ -43,13 +42,8 @@ using Op = std::function<hipError_t(hipStream_t)>;
 
 struct fdm_prog {
   std::vector<Op> ops;
-  std::vector<int> lane;        // lane (independent chain) of each op; lanes run as parallel graph branches
-  int cur_lane = 0, n_lanes = 1;
-  std::vector<hipStream_t> lane_streams;     // one per lane when n_lanes > 1
-  std::vector<hipEvent_t> lane_events;
-  hipEvent_t fork_event = nullptr;
-  std::vector<hipGraph_t> graphs;            // one captured graph per lane
-  std::vector<hipGraphExec_t> execs;
+  hipGraph_t graph = nullptr;                // the captured sequence
+  hipGraphExec_t exec = nullptr;
 };
 
 namespace {
@@ -60,7 +54,6 @@ thread_local fdm_prog* g_rec = nullptr;
 int submit(Op op, void* stream, const char* what) {
   if (g_rec) {
     g_rec->ops.push_back(std::move(op));
-    g_rec->lane.push_back(g_rec->cur_lane);
     return FDM_OK;
   }
   hipError_t e = op((hipStream_t)stream);
@@ -82,7 +75,7 @@ int grid_for(long long n) {
 extern "C" {
 
 const char* fdm_last_error(void) { return g_err.c_str(); }
-int fdm_version(void) { return 104; }      // 1.04: round 4 (fdm_op_conv0_ln_gelu, fdm_op_time_groupnorm scratch + split outputs, FDM_TILE_GENERAL, 96x128 retired, needs_tune)
+int fdm_version(void) { return 105; }      // 1.05: round 5 (fdm_gemm_args.ksplit / batch2, fdm_ln_args.x_planes, plan keys ksplit.*; lanes, FDM_BF16X3 and three tile ids removed)
 
 // sizeof() of a public struct as THIS build sees it: a binding compares it with its own mirror before the first call
 int fdm_abi_struct_size(const char* name) {
@@ -111,8 +104,8 @@ static bool gemm_act_heavy_host(int act) { return act == FDM_ACT_MISH || act == 
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W) return fail(FDM_ERR_ARG, "gemm: null operand");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return fail(FDM_ERR_SHAPE, "gemm: M,N,K must be positive (%d,%d,%d)", a->M, a->N, a->K);
-  if (a->dtype < FDM_F32 || a->dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "gemm: bad dtype %d", a->dtype);
-  const bool split = a->dtype == FDM_F16X3 || a->dtype == FDM_BF16X3;
+  if (a->dtype < FDM_F32 || a->dtype > FDM_F16X3) return fail(FDM_ERR_ARG, "gemm: bad dtype %d", a->dtype);
+  const bool split = a->dtype == FDM_F16X3;
   const int bk = a->dtype == FDM_F32 ? 32 : 64, epc = a->dtype == FDM_F32 ? 4 : 8;
   if (split && (a->a_lo_off <= 0 || a->w_lo_off <= 0 || a->a_lo_off % epc || a->w_lo_off % epc))
     return fail(FDM_ERR_ARG, "gemm: split operands need positive a_lo_off / w_lo_off (multiples of 8 elements)");
@@ -151,7 +144,6 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (a->ksplit < 0 || a->ksplit > 4) return fail(FDM_ERR_ARG, "gemm: ksplit %d outside 0..4", a->ksplit);
   if (a->ksplit > 1) {
     const int tl = a->tile & ~FDM_TILE_GENERAL;
-    if (a->dtype == FDM_BF16X3) return fail(FDM_ERR_ARG, "gemm: ksplit is not offered for the bf16x3 comparison kind");
     if (a->batch > 1 || a->out_batch_stride || a->act != FDM_ACT_NONE || !a->out_f32 || a->out_t || a->out_kp || a->out_vp || a->stat_out || a->ln_stat_in ||
         a->sched_fuse || a->resid_row_mod || (a->tile & FDM_TILE_GENERAL))
       return fail(FDM_ERR_ARG, "gemm: ksplit needs a plain launch (one batch, no activation, out_f32 as the only output, no folds)");
@@ -159,18 +151,17 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
     if (a->N % 64 || a->ldo_f32 % 4 || !aligned16(a->out_f32) || a->ksplit_stride % 4 || a->ksplit_stride < (long long)(a->M - 1) * a->ldo_f32 + a->N ||
         (a->resid && (a->ldr % 4 || !aligned16(a->resid))))
       return fail(FDM_ERR_SHAPE, "gemm: ksplit needs N %% 64 == 0, 16-byte aligned rows and ksplit_stride >= one output plane");
-    if (tl != 0 && tl != FDM_TILE_64x64 && tl != FDM_TILE_64x64_S3 && tl != FDM_TILE_64x64_S2 && tl != FDM_TILE_32x64_S3)
-      return fail(FDM_ERR_ARG, "gemm: ksplit runs on the 64-column tiles (FDM_TILE_64x64, _S3, _S2, FDM_TILE_32x64_S3), not tile %d", tl);
+    if (tl != 0 && tl != FDM_TILE_64x64 && tl != FDM_TILE_64x64_S2 && tl != FDM_TILE_32x64_S3)
+      return fail(FDM_ERR_ARG, "gemm: ksplit runs on the 64-column tiles (FDM_TILE_64x64, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3), not tile %d", tl);
   }
   if (a->batch2 < 0) return fail(FDM_ERR_ARG, "gemm: negative batch2");
   if (a->batch2 >= 1) {
     const int tl = a->tile & ~FDM_TILE_GENERAL;
-    if (a->dtype == FDM_BF16X3) return fail(FDM_ERR_ARG, "gemm: batch2 is not offered for the bf16x3 comparison kind");
     if (a->ksplit > 1 || a->out_kp || a->out_vp || a->stat_out || a->ln_stat_in || a->sched_fuse || a->resid_row_mod || a->incr_counter)
       return fail(FDM_ERR_ARG, "gemm: batch2 cannot be combined with ksplit, packed K/V, LayerNorm folds, the fused scheduler or resid_row_mod");
     if (a->a_batch_stride2 % epc) return fail(FDM_ERR_ARG, "gemm: a_batch_stride2 needs 16-byte alignment");
-    if (tl != 0 && tl != FDM_TILE_64x64 && tl != FDM_TILE_64x64_S3 && tl != FDM_TILE_64x64_S2 && tl != FDM_TILE_128x64 && tl != FDM_TILE_128x64_S3)
-      return fail(FDM_ERR_ARG, "gemm: batch2 runs on the 64-column tiles (FDM_TILE_64x64, _S3, _S2, FDM_TILE_128x64, _S3), not tile %d", tl);
+    if (tl != 0 && tl != FDM_TILE_64x64 && tl != FDM_TILE_64x64_S2 && tl != FDM_TILE_128x64)
+      return fail(FDM_ERR_ARG, "gemm: batch2 runs on the 64-column tiles (FDM_TILE_64x64, FDM_TILE_64x64_S2, FDM_TILE_128x64), not tile %d", tl);
   }
   fdm_gemm_args c = *a;
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");
@@ -187,7 +178,7 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream) {
   if (a->B <= 0 || a->H <= 0 || a->L <= 0) return fail(FDM_ERR_SHAPE, "attention: B,H,L must be positive");
   if (a->Lpad < a->L || a->Lpad % 32) return fail(FDM_ERR_SHAPE, "attention: Lpad=%d must be a multiple of 32 >= L", a->Lpad);
   if (a->dtype != FDM_F32 && a->dtype != FDM_BF16 && a->dtype != FDM_F16X3) return fail(FDM_ERR_ARG, "attention: bad dtype %d (FDM_F32, FDM_BF16, FDM_F16X3)", a->dtype);
-  if (a->o_split && (a->dtype != FDM_F32 || (a->o_split != FDM_F16X3 && a->o_split != FDM_BF16X3) || a->o_lo_off <= 0))
+  if (a->o_split && (a->dtype != FDM_F32 || a->o_split != FDM_F16X3 || a->o_lo_off <= 0))
     return fail(FDM_ERR_ARG, "attention: o_split needs dtype FDM_F32, a split kind and o_lo_off");
   if (a->dtype == FDM_F16X3 && (a->q_lo_off <= 0 || a->kv_lo_off <= 0 || a->o_lo_off <= 0 || a->q_lo_off % 8 || a->kv_lo_off % 8 || a->o_lo_off % 4))
     return fail(FDM_ERR_ARG, "attention: split operands need q_lo_off, kv_lo_off and o_lo_off");
@@ -215,7 +206,7 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
   if (a->d != 256 && a->d != 512 && a->d != 768 && a->d != 1024) return fail(FDM_ERR_SHAPE, "layernorm: d=%d unsupported (256, 512, 768, 1024)", a->d);
   if (a->M <= 0) return fail(FDM_ERR_SHAPE, "layernorm: M must be positive");
   if (!a->y_f32 && !a->y_t) return fail(FDM_ERR_ARG, "layernorm: no output");
-  if (a->dtype < FDM_F32 || a->dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "layernorm: bad dtype %d", a->dtype);
+  if (a->dtype < FDM_F32 || a->dtype > FDM_F16X3) return fail(FDM_ERR_ARG, "layernorm: bad dtype %d", a->dtype);
   if (a->y_t && a->dtype >= FDM_F16X3 && (a->y_t_lo_off <= 0 || a->y_t_lo_off % 4)) return fail(FDM_ERR_ARG, "layernorm: split y_t needs y_t_lo_off");
   if (a->add_mat_group < 0 || a->add_mat_wrap < 0 ||
       (a->add_mat_group > 0 && (a->add_mat_L <= 0 || a->add_mat_group % a->add_mat_L || (a->add_mat_wrap > 0 && a->add_mat_wrap % a->add_mat_group))))
@@ -227,7 +218,6 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
     switch (c.dtype) {
       case FDM_BF16: return fdm::ln_launch_t<fdm::bf16>(c, s);
       case FDM_F16X3: return fdm::ln_launch_t<fdm::f16x3_t>(c, s);
-      case FDM_BF16X3: return fdm::ln_launch_t<fdm::bf16x3_t>(c, s);
       default: return fdm::ln_launch_t<float>(c, s);
     }
   }, stream, "layernorm");
@@ -247,12 +237,11 @@ int fdm_op_sched_step(const fdm_sched_args* a, void* stream) {
 
 int fdm_op_cast(const float* src, void* dst, long long n, int dtype, void* stream) {
   if (!src || !dst || n <= 0) return fail(FDM_ERR_ARG, "cast: bad argument");
-  if (dtype < FDM_F32 || dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "cast: bad dtype %d", dtype);
+  if (dtype < FDM_F32 || dtype > FDM_F16X3) return fail(FDM_ERR_ARG, "cast: bad dtype %d", dtype);
   return submit([=](hipStream_t s) {
     const dim3 g(grid_for(n)), b(256);
     if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::cast_kernel<fdm::bf16>), g, b, 0, s, src, (fdm::bf16*)dst, n);
     else if (dtype == FDM_F16X3) hipLaunchKernelGGL((fdm::cast_kernel<fdm::f16x3_t>), g, b, 0, s, src, (fdm::f16*)dst, n);
-    else if (dtype == FDM_BF16X3) hipLaunchKernelGGL((fdm::cast_kernel<fdm::bf16x3_t>), g, b, 0, s, src, (fdm::bf16*)dst, n);
     else hipLaunchKernelGGL((fdm::cast_kernel<float>), g, b, 0, s, src, (float*)dst, n);
     return hipGetLastError();
   }, stream, "cast");
@@ -454,11 +443,8 @@ int fdm_prog_create(fdm_prog** out) {
 int fdm_prog_destroy(fdm_prog* p) {
   if (!p) return FDM_OK;
   if (g_rec == p) g_rec = nullptr;
-  for (auto x : p->execs) (void)hipGraphExecDestroy(x);
-  for (auto g : p->graphs) (void)hipGraphDestroy(g);
-  for (auto e : p->lane_events) (void)hipEventDestroy(e);
-  if (p->fork_event) (void)hipEventDestroy(p->fork_event);
-  for (auto st : p->lane_streams) (void)hipStreamDestroy(st);
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
   delete p;
   return FDM_OK;
 }
@@ -466,7 +452,7 @@ int fdm_prog_destroy(fdm_prog* p) {
 int fdm_prog_begin(fdm_prog* p) {
   if (!p) return fail(FDM_ERR_ARG, "prog_begin: null program");
   if (g_rec) return fail(FDM_ERR_STATE, "prog_begin: another program is recording on this thread");
-  if (!p->execs.empty()) return fail(FDM_ERR_STATE, "prog_begin: program already instantiated");
+  if (p->exec) return fail(FDM_ERR_STATE, "prog_begin: program already instantiated");
   g_rec = p;
   return FDM_OK;
 }
@@ -478,14 +464,6 @@ int fdm_prog_end(fdm_prog* p) {
 }
 
 int fdm_prog_num_ops(fdm_prog* p) { return p ? (int)p->ops.size() : 0; }
-
-int fdm_prog_set_lane(fdm_prog* p, int lane) {
-  if (!p || g_rec != p) return fail(FDM_ERR_STATE, "prog_set_lane: program is not recording");
-  if (lane < 0 || lane >= 64) return fail(FDM_ERR_ARG, "prog_set_lane: lane %d outside [0, 64)", lane);
-  p->cur_lane = lane;
-  if (lane + 1 > p->n_lanes) p->n_lanes = lane + 1;
-  return FDM_OK;
-}
 
 int fdm_prog_run(fdm_prog* p, void* stream) {
   if (!p) return fail(FDM_ERR_ARG, "prog_run: null program");
@@ -500,132 +478,39 @@ int fdm_prog_run(fdm_prog* p, void* stream) {
 int fdm_prog_instantiate(fdm_prog* p, void* stream) {
   if (!p) return fail(FDM_ERR_ARG, "prog_instantiate: null program");
   if (g_rec) return fail(FDM_ERR_STATE, "prog_instantiate: a program is still recording");
-  if (!p->execs.empty()) return FDM_OK;
+  if (p->exec) return FDM_OK;
   if (p->ops.empty()) return fail(FDM_ERR_STATE, "prog_instantiate: empty program");
-  hipError_t e;
-  // One graph per lane.  Lanes are dependency-free chains; each lane's graph is replayed on its own
-  // stream so that the chains overlap on the device (parallel branches inside ONE hipGraph are executed
-  // back to back by the ROCm 7.2 graph executor -- measured -- so the fork is made across streams instead).
-  if (p->n_lanes > 1 && p->lane_streams.empty()) {
-    if ((e = hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-    for (int i = 0; i < p->n_lanes; ++i) {
-      hipStream_t st; hipEvent_t ev;
-      if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
-      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-      p->lane_streams.push_back(st);
-      p->lane_events.push_back(ev);
-    }
-  }
+  (void)stream;
   // Capture never executes anything, so it runs on a stream of the library's own: the caller's stream may be the legacy
-  // default stream (torch's current stream usually is), which cannot be captured.
+  // default stream (torch's current stream usually is), which cannot be captured.  (Independent chains as parallel branches
+  // of one graph, or as graphs on separate streams, were measured slower than one chain over all rows -- rounds 1 and 3,
+  // profiles/README.md -- and are no longer offered.)
   hipStream_t cap = nullptr;
-  if (p->n_lanes == 1 && (e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
+  hipError_t e = hipStreamCreateWithFlags(&cap, hipStreamNonBlocking);
+  if (e != hipSuccess) return hip_fail(e, "hipStreamCreate");
   struct CapGuard { hipStream_t s; ~CapGuard() { if (s) (void)hipStreamDestroy(s); } } guard{cap};
-  for (int ln = 0; ln < p->n_lanes; ++ln) {
-    hipStream_t s = p->n_lanes > 1 ? p->lane_streams[ln] : cap;
-    e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
-    hipError_t opErr = hipSuccess;
-    int n_ops = 0;
-    for (size_t i = 0; opErr == hipSuccess && i < p->ops.size(); ++i)
-      if (p->lane[i] == ln) { opErr = p->ops[i](s); ++n_ops; }
-    hipGraph_t g = nullptr;
-    e = hipStreamEndCapture(s, &g);
-    // a failure part-way leaves no half-built state behind: a later instantiate starts over, replay keeps failing loudly
-    auto cleanup = [&] {
-      for (auto x2 : p->execs) (void)hipGraphExecDestroy(x2);
-      for (auto g2 : p->graphs) (void)hipGraphDestroy(g2);
-      p->execs.clear(); p->graphs.clear();
-    };
-    if (opErr != hipSuccess) { if (g) (void)hipGraphDestroy(g); cleanup(); return hip_fail(opErr, "prog_instantiate (launch during capture)"); }
-    if (e != hipSuccess) { cleanup(); return hip_fail(e, "hipStreamEndCapture"); }
-    if (n_ops == 0) { (void)hipGraphDestroy(g); cleanup(); return fail(FDM_ERR_STATE, "prog_instantiate: lane %d has no ops", ln); }
-    hipGraphExec_t x = nullptr;
-    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
-    if (e != hipSuccess) { (void)hipGraphDestroy(g); cleanup(); return hip_fail(e, "hipGraphInstantiate"); }
-    p->graphs.push_back(g);
-    p->execs.push_back(x);
-  }
+  e = hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return hip_fail(e, "hipStreamBeginCapture");
+  hipError_t opErr = hipSuccess;
+  for (size_t i = 0; opErr == hipSuccess && i < p->ops.size(); ++i) opErr = p->ops[i](cap);
+  hipGraph_t g = nullptr;
+  e = hipStreamEndCapture(cap, &g);
+  // a failure part-way leaves no half-built state behind: a later instantiate starts over, replay keeps failing loudly
+  if (opErr != hipSuccess) { if (g) (void)hipGraphDestroy(g); return hip_fail(opErr, "prog_instantiate (launch during capture)"); }
+  if (e != hipSuccess) return hip_fail(e, "hipStreamEndCapture");
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) { (void)hipGraphDestroy(g); return hip_fail(e, "hipGraphInstantiate"); }
+  p->graph = g;
+  p->exec = x;
   return FDM_OK;
 }
 
 int fdm_prog_replay(fdm_prog* p, int n, void* stream) {
-  if (!p || p->execs.empty()) return fail(FDM_ERR_STATE, "prog_replay: program not instantiated");
-  hipStream_t s = (hipStream_t)stream;
-  hipError_t e;
-  if (p->n_lanes == 1) {
-    for (int i = 0; i < n; ++i)
-      if ((e = hipGraphLaunch(p->execs[0], s)) != hipSuccess) return hip_fail(e, "hipGraphLaunch");
-    return FDM_OK;
-  }
-  // fork: every lane stream waits for the work already queued on the caller's stream
-  if ((e = hipEventRecord(p->fork_event, s)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-  for (auto st : p->lane_streams)
-    if ((e = hipStreamWaitEvent(st, p->fork_event, 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
-  // lanes free-run for all n replays (no per-step join: chains share nothing, not even the step counter).
-  // Graph launch costs the host a few microseconds per kernel node, so each lane is fed by its own
-  // host thread; otherwise one thread feeding L lanes would be the bottleneck.
-  {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::vector<hipError_t> errs(p->n_lanes, hipSuccess);
-    std::vector<std::thread> th;
-    for (int ln = 0; ln < p->n_lanes; ++ln)
-      th.emplace_back([p, ln, n, dev, &errs] {
-        hipError_t er = hipSetDevice(dev);
-        for (int i = 0; er == hipSuccess && i < n; ++i) er = hipGraphLaunch(p->execs[ln], p->lane_streams[ln]);
-        errs[ln] = er;
-      });
-    for (auto& t : th) t.join();
-    for (auto er : errs)
-      if (er != hipSuccess) return hip_fail(er, "hipGraphLaunch (lane thread)");
-  }
-  // join
-  for (int ln = 0; ln < p->n_lanes; ++ln) {
-    if ((e = hipEventRecord(p->lane_events[ln], p->lane_streams[ln])) != hipSuccess) return hip_fail(e, "hipEventRecord");
-    if ((e = hipStreamWaitEvent(s, p->lane_events[ln], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
-  }
-  return FDM_OK;
-}
-
-// Experiment / fallback: run every lane's ops eagerly n times, each lane on its own stream fed by its own
-// host thread (no hipGraph).  Lanes are joined into `stream` at the end.
-int fdm_prog_run_lanes(fdm_prog* p, int n, void* stream) {
-  if (!p) return fail(FDM_ERR_ARG, "prog_run_lanes: null program");
-  if (g_rec) return fail(FDM_ERR_STATE, "prog_run_lanes: a program is still recording");
-  hipStream_t s = (hipStream_t)stream;
-  hipError_t e;
-  if (p->lane_streams.empty()) {
-    if ((e = hipEventCreateWithFlags(&p->fork_event, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-    for (int i = 0; i < p->n_lanes; ++i) {
-      hipStream_t st; hipEvent_t ev;
-      if ((e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) return hip_fail(e, "hipStreamCreate");
-      if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return hip_fail(e, "hipEventCreate");
-      p->lane_streams.push_back(st);
-      p->lane_events.push_back(ev);
-    }
-  }
-  if ((e = hipEventRecord(p->fork_event, s)) != hipSuccess) return hip_fail(e, "hipEventRecord");
-  for (auto st : p->lane_streams)
-    if ((e = hipStreamWaitEvent(st, p->fork_event, 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  std::vector<hipError_t> errs(p->n_lanes, hipSuccess);
-  std::vector<std::thread> th;
-  for (int ln = 0; ln < p->n_lanes; ++ln)
-    th.emplace_back([p, ln, n, dev, &errs] {
-      hipError_t er = hipSetDevice(dev);
-      for (int it = 0; er == hipSuccess && it < n; ++it)
-        for (size_t i = 0; er == hipSuccess && i < p->ops.size(); ++i)
-          if (p->lane[i] == ln) er = p->ops[i](p->lane_streams[ln]);
-      errs[ln] = er;
-    });
-  for (auto& t : th) t.join();
-  for (auto er : errs)
-    if (er != hipSuccess) return hip_fail(er, "prog_run_lanes");
-  for (int ln = 0; ln < p->n_lanes; ++ln) {
-    if ((e = hipEventRecord(p->lane_events[ln], p->lane_streams[ln])) != hipSuccess) return hip_fail(e, "hipEventRecord");
-    if ((e = hipStreamWaitEvent(s, p->lane_events[ln], 0)) != hipSuccess) return hip_fail(e, "hipStreamWaitEvent");
+  if (!p || !p->exec) return fail(FDM_ERR_STATE, "prog_replay: program not instantiated");
+  for (int i = 0; i < n; ++i) {
+    const hipError_t e = hipGraphLaunch(p->exec, (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipGraphLaunch");
   }
   return FDM_OK;
 }

@@ -7,7 +7,7 @@
 //    are 128 B with a 16-byte-chunk XOR swizzle (chunk ^ (row & 7)) so that the ds_read_b128 fragment reads
 //    of 16 different rows at one k-chunk spread over 8 slots.
 //  * Operand kinds (common.hpp, Opnd<T>): fp32 (exact, v_mfma_f32_16x16x4_f32), bf16 (v_mfma_f32_16x16x32_bf16),
-//    and the split kinds f16x3 / bf16x3: hi and lo planes of both operands ride the same ring (a stage holds
+//    and the split kind f16x3: hi and lo planes of both operands ride the same ring (a stage holds
 //    A_hi, A_lo, W_hi, W_lo) and every fragment pair takes three 16-bit MFMAs (hi.hi into the main accumulator,
 //    hi.lo + lo.hi into a second one that is scaled by 1 / SCALE once, after the k loop).
 //  * Operands are swapped into the MFMA (W rows feed the A port, activation rows the B port), so a
@@ -988,12 +988,13 @@ static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
 
 template <typename T, int BM, int BN, int WM, int WN, int NST>
 static hipError_t gemm_pp_launch_t(const fdm_gemm_args& a, hipStream_t s) {
+  const bool no_lean = (a.tile & FDM_TILE_GENERAL) != 0;      // tests: the edge-handling kernel on a shape that does not need it
   if (gemm_act_is_heavy(a.act)) {
-    if (!a.out_kp && !a.out_vp && !a.stat_out && !a.ln_stat_in && gemm_all_tiles_lean<T, BM, BN>(a))
+    if (!no_lean && !a.out_kp && !a.out_vp && !a.stat_out && !a.ln_stat_in && gemm_all_tiles_lean<T, BM, BN>(a))
       return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, true, false, GEMM_LEAN>(a, s);
     return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, true>(a, s);
   }
-  if (gemm_all_tiles_lean<T, BM, BN>(a)) {
+  if (!no_lean && gemm_all_tiles_lean<T, BM, BN>(a)) {
     const bool kv = a.out_kp || a.out_vp, fold = a.stat_out || a.ln_stat_in;
     if (kv && fold) return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, false, false, GEMM_LEAN | GEMM_KV | GEMM_FOLD>(a, s);
     if (kv) return gemm_pp_launch_h<T, BM, BN, WM, WN, NST, false, false, GEMM_LEAN | GEMM_KV>(a, s);
@@ -1026,7 +1027,7 @@ static bool gemm_one_round_80(const fdm_gemm_args& a) {
 static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool split) {
   if (a.batch2 >= 1) {       // grouped conv over clips: 128-row tiles once they fill the chip (one round of 256: 4 row tiles x 16 groups x 4 clips), else 64
     const long long t128b = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * (a.batch > 0 ? a.batch : 1) * a.batch2;
-    return t128b >= 192 ? (split ? FDM_TILE_128x64_S3 : FDM_TILE_128x64) : FDM_TILE_64x64;
+    return t128b >= 192 ? FDM_TILE_128x64 : FDM_TILE_64x64;
   }
   const long long batch = a.batch > 0 ? a.batch : 1;
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
@@ -1042,8 +1043,9 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
     const bool pp_ok = elem_bytes == 2 && a.N % 128 == 0 && a.K >= 1024;
     if (pp_ok && a.M >= 6000 && a.N <= 2048 && t256 >= 150) return FDM_TILE_256x128_PP;
     // a wide projection whose 256x128 grid is exactly one round (HuBERT's FFN1 at 4 x 10 s: 1992 x 4096 = 8 x 32 tiles; 29.6 us
-    // against 33.3 on the 512 tiles of 128x128, profiles/r4_pmc_hubert)
-    if (elem_bytes == 2 && a.M > 1024 && t128 >= thr128 && gemm_one_round(t256)) return FDM_TILE_256x128;
+    // against 33.3 on the 512 tiles of 128x128, profiles/r4_pmc_hubert; the lockstep 256x128 kernel of rounds 2-4 measured 29.9 against
+    // 29.4 for the ping-pong loop there and is retired: profiles/r5_xcd_band/gemm_tiles_hubert_ffn.txt)
+    if (elem_bytes == 2 && a.M > 1024 && t128 >= thr128 && gemm_one_round(t256)) return FDM_TILE_256x128_PP;
     if (t128 >= thr128) return FDM_TILE_128x128;
     if (gemm_one_round_80(a)) return FDM_TILE_80x128;
     // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two
@@ -1053,9 +1055,8 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
       // A grid that fills the chip in exactly ONE round wins; else 128x64 -- on the 4-stage ring while its grid is one round, on the
       // 3-stage ring (72 KB: two workgroups per CU, all of <= 512 tiles resident) beyond.
       if (gemm_one_round(t128)) return FDM_TILE_128x128;
-      if (pp_ok && gemm_one_round(t256) && a.M >= 3000) return FDM_TILE_256x128_PP;
-      if (gemm_one_round(t256)) return FDM_TILE_256x128;
-      if (t128x64 > 128) return t128x64 <= 256 ? FDM_TILE_128x64 : FDM_TILE_128x64_S3;
+      if (gemm_one_round(t256)) return FDM_TILE_256x128_PP;
+      if (t128x64 > 128) return FDM_TILE_128x64;          // (4-stage ring while its grid is one round, 3-stage beyond: the tile picks)
     }
     if (t128x64 >= thr128x64) return FDM_TILE_128x64;
     return FDM_TILE_64x64;
@@ -1064,14 +1065,14 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
   if (gemm_one_round_80(a)) return FDM_TILE_80x128;
   if (a.M > 1024) {            // the tuner's picks at 1100..4000 rows as rules (see above)
     if (gemm_one_round(t128)) return FDM_TILE_128x128;
-    if (t128x64 > 128 && t128x64 <= 256) return FDM_TILE_128x64_S3;     // (144 KB ring: one per CU, so one round only)
+    if (t128x64 > 128 && t128x64 <= 256) return FDM_TILE_128x64;     // (split kinds: 3-stage, 144 KB ring -- one per CU, so one round only)
   } else {
     // a single short clip: 64x64 tiles leave half the CUs idle -> 32-row tiles (72 KB rings, two per CU); 257..512 tiles of a
     // wide projection: the 2-stage ring (64 KB) keeps all of them resident in one round instead of two
     if (t64 <= 128) return FDM_TILE_32x64_S3;
     if (t64 > 256 && t64 <= 512 && a.N >= 2048) return FDM_TILE_64x64_S2;
   }
-  if (t128x64 >= 700) return FDM_TILE_128x64_S3;
+  if (t128x64 >= 700) return FDM_TILE_128x64;
   return FDM_TILE_64x64;
 }
 
@@ -1088,7 +1089,6 @@ static int gemm_ksplit_heuristic_tile(const fdm_gemm_args& a) { return a.M <= 12
 template <typename T>
 static hipError_t gemm_dispatch_ksplit(const fdm_gemm_args& a, int tile_id, hipStream_t s) {
   switch (tile_id > 0 ? tile_id : gemm_ksplit_heuristic_tile(a)) {
-    case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);
     case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);
     case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);
     default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);
@@ -1110,14 +1110,17 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
   const int want = tile_id > 0 ? tile_id : gemm_tile_override();
   switch (want > 0 ? want : gemm_heuristic_tile(a, (int)sizeof(typename Opnd<T>::E), false)) {
-    case FDM_TILE_128x64: return gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s);    // 8 waves, 32x32 per wave
+    case FDM_TILE_128x64_S3:                                                       // (retired id: the tile picks its ring depth)
+    case FDM_TILE_128x64: {                                                        // 8 waves, 32x32 per wave
+      // 4-stage ring (96 KB, one per CU) while the grid is one round; beyond that the 3-stage ring (72 KB): two workgroups per CU
+      const long long wgs = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * (a.batch > 0 ? a.batch : 1) * (a.batch2 > 0 ? a.batch2 : 1);
+      return wgs <= 256 ? gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s) : gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);
+    }
     case FDM_TILE_96x128:                                                          // (retired id: nearest member)
     case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);  // 8 waves, 64x32 per wave
-    case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);   // 3-stage ring: 48 KB -> 3 workgroups per CU
-    case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
     case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 32 KB -> 4 workgroups per CU
     case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);    // 4 waves, 16x32 per wave, 36 KB
-    case FDM_TILE_256x128: return gemm_glds_launch_t<T, 256, 128, 4, 2, 3>(a, s);  // 8 waves, 64x64 per wave, 146 KB LDS
+    case FDM_TILE_256x128:                                                           // (retired id: the lockstep loop on this tile)
     case FDM_TILE_256x128_PP: return gemm_pp_launch_t<T, 256, 128, 4, 2, 3>(a, s);   // ping-pong loop, 64x64 per wave, 146 KB
     case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);      // 8 waves, 80x16 per wave: 800 rows x 3072 = 240 workgroups
     case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4>(a, s);      // 8 waves, 32x32 per wave
@@ -1132,26 +1135,21 @@ static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
   if (a.sched_fuse)
     return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
                         : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
-  if constexpr (std::is_same<T, bf16x3_t>::value) {
-    return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                          // comparison mode: one tile
-  } else {
-    const int tile_id = a.tile & ~FDM_TILE_GENERAL;
-    if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
-    const int want = tile_id > 0 ? tile_id : gemm_tile_override();
-    switch (want > 0 ? want : gemm_heuristic_tile(a, 2, true)) {
-      case FDM_TILE_64x64_S3: return gemm_glds_launch_t<T, 64, 64, 2, 4, 3>(a, s);  // 96 KB
-      case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);  // 64 KB -> 2 workgroups per CU
-      case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
-      case FDM_TILE_128x64:
-      case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);   // 144 KB
-      case FDM_TILE_128x128:
-      case FDM_TILE_96x128:
-      case FDM_TILE_256x128:
-      case FDM_TILE_256x128_PP: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);    // 128 KB, one tile in flight
-      case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);      // 156 KB
-      case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 3>(a, s);      // 144 KB
-      default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                    // FDM_TILE_64x64: 128 KB ring
-    }
+  const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+  if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
+  const int want = tile_id > 0 ? tile_id : gemm_tile_override();
+  switch (want > 0 ? want : gemm_heuristic_tile(a, 2, true)) {
+    case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);  // 64 KB -> 2 workgroups per CU
+    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
+    case FDM_TILE_128x64:
+    case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);   // 144 KB
+    case FDM_TILE_128x128:
+    case FDM_TILE_96x128:
+    case FDM_TILE_256x128:
+    case FDM_TILE_256x128_PP: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);    // 128 KB, one tile in flight
+    case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);      // 156 KB
+    case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 3>(a, s);      // 144 KB
+    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                    // FDM_TILE_64x64: 128 KB ring
   }
 }
 

@@ -6,7 +6,6 @@ namespace fdm { hipError_t gemm_launch_bf16(const fdm_gemm_args& a, hipStream_t 
 namespace fdm {
 int gemm_heuristic_tile_of(const fdm_gemm_args& a) {
   if (a.ksplit > 1) return gemm_ksplit_heuristic_tile(a);
-  if (a.dtype == FDM_BF16X3) return FDM_TILE_64x64;
   if (a.sched_fuse) {        // two forms: 64x64, and the ping-pong tile (one-plane kinds, whole column tiles)
     const bool pp = a.dtype != FDM_F16X3 && gemm_tile_override() == 0 && !a.ln_stat_in && a.N % 128 == 0 && gemm_sched_fuse_heuristic_pp(a, a.dtype == FDM_F32 ? 4 : 2);
     return pp ? FDM_TILE_256x128_PP : FDM_TILE_64x64;

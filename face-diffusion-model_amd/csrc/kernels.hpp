@@ -9,7 +9,6 @@ int fail(int code, const char* fmt, ...);      // fdm_hip.hip: sets the thread's
 hipError_t gemm_launch_f32(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_bf16(const fdm_gemm_args& a, hipStream_t s);
 hipError_t gemm_launch_f16x3(const fdm_gemm_args& a, hipStream_t s);
-hipError_t gemm_launch_bf16x3(const fdm_gemm_args& a, hipStream_t s);
 int gemm_heuristic_tile_of(const fdm_gemm_args& a);      // gemm_bf16.hip: the tile a launch with tile = 0 resolves to
 hipError_t attn_launch_f32(const fdm_attn_args& a, hipStream_t s);
 hipError_t attn_launch_bf16(const fdm_attn_args& a, hipStream_t s);
@@ -21,7 +20,6 @@ inline hipError_t gemm_launch(const fdm_gemm_args& a, hipStream_t s) {
   switch (a.dtype) {
     case FDM_BF16: return gemm_launch_bf16(a, s);
     case FDM_F16X3: return gemm_launch_f16x3(a, s);
-    case FDM_BF16X3: return gemm_launch_bf16x3(a, s);
     default: return gemm_launch_f32(a, s);
   }
 }

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -234,6 +235,7 @@ struct fdm_plan {
   std::map<std::string, std::vector<fdm_gemm_args>>* tune_rec = nullptr;
   int tune_enabled = 1;
   int tune_failed = 0;                       // opt-in request-path tuning runs that failed (heuristic tiles kept)
+  std::set<std::string> tune_failed_shapes;  // ... and their shapes: the request path tries a shape once (fdm_plan_tune retries)
   int want_fuse_ln3 = 0;                     // fdm_plan_set "fuse_ln3": fold norm3 into the GEMMs around it at the next commit
   // K slices of the two GEMMs whose fp32 output row is read next by a LayerNorm launch (out-proj -> LN1+LN2, FFN2 -> LN3): S > 1 = S
   // partial planes of x1, summed by that launch (fdm_gemm_args.ksplit / fdm_ln_args.x_planes).  A property of the plan, NOT of the
@@ -246,7 +248,7 @@ struct fdm_plan {
 namespace {
 
 size_t esize(int dtype) { return dtype == FDM_F32 ? 4 : 2; }
-bool is_split(int dtype) { return dtype == FDM_F16X3 || dtype == FDM_BF16X3; }
+bool is_split(int dtype) { return dtype == FDM_F16X3; }
 
 int dalloc(fdm_plan* P, void** out, size_t bytes, bool ws, bool zero = true) {
   void* p = nullptr;
@@ -522,7 +524,7 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   }
   // q: row-major queries; kp / vp: fragment-packed keys / values written by the QKV GEMM's epilogue (zeroed: pad keys must be
   // finite).  Split modes: attention runs in fp32, ctx returns as a plane pair.
-  // (FDM_F16X3: fp16 plane pairs, the same bytes as fp32; FDM_BF16X3: fp32, attention runs in fp32)
+  // (FDM_F16X3: fp16 plane pairs, the same bytes as fp32)
   const size_t ea = P->dtype == FDM_BF16 ? 2 : 4;
   FCK(dalloc(P, &P->q, R * d * ea, true));
   FCK(dalloc(P, &P->kp, (size_t)B * repc * Lpad * d * ea, true));
@@ -583,21 +585,18 @@ int record_chain(fdm_plan* P, const fdm_sched_args* sched, void* stream) {
       g.bias = f->bias; g.ln_stat_in = P->stats; g.ln_nparts = np; g.ln_dim = d; g.ln_eps = eps; g.ln_colsum = f->colsum;
     }
     // FDM_F16X3: split attention on plane pairs (head_dim 64 / 128 hold a key tile's fragments in registers, 256 -- BIWI --
-    // streams them at one wave per SIMD).  FDM_BF16X3 (comparison mode): fp32 attention.
-    const bool split_attn = P->dtype == FDM_F16X3;
-    if (split && !split_attn) { g.out_f32 = (float*)P->q; g.ldo_f32 = d; }
-    else { g.out_t = P->q; g.ldo_t = d; g.out_t_lo_off = split_attn ? P->q_lo : 0; }
-    g.kv_lo_off = split_attn ? P->kv_lo : 0;
+    // streams them at one wave per SIMD).
+    g.out_t = P->q; g.ldo_t = d; g.out_t_lo_off = split ? P->q_lo : 0;
+    g.kv_lo_off = split ? P->kv_lo : 0;
     g.out_kp = P->kp; g.kp_col0 = d; g.out_vp = P->vp; g.vp_col0 = 2 * d; g.kv_L = L; g.kv_Lpad = P->Lpad; g.kv_hd = P->hd;
     FCK(plan_gemm(P, f ? "qkv_ln" : "qkv", g, stream));
     fdm_attn_args at;
     memset(&at, 0, sizeof(at));
     at.Q = P->q; at.ldq = d;
     at.Kp = P->kp; at.Vp = P->vp; at.Lpad = P->Lpad; at.O = P->ctx.p; at.ldo = d;
-    at.B = BB; at.H = m.n_head; at.L = L; at.hd = P->hd; at.dtype = split_attn ? FDM_F16X3 : (split ? FDM_F32 : P->dtype);
+    at.B = BB; at.H = m.n_head; at.L = L; at.hd = P->hd; at.dtype = P->dtype;
     at.scale = 1.0f / std::sqrt((float)P->hd); at.causal = 1; at.slopes = P->slopes; at.period = m.period;
-    if (split_attn) { at.q_lo_off = P->q_lo; at.kv_lo_off = P->kv_lo; at.o_lo_off = P->ctx.lo; }
-    else if (split) { at.o_split = P->dtype; at.o_lo_off = P->ctx.lo; }
+    if (split) { at.q_lo_off = P->q_lo; at.kv_lo_off = P->kv_lo; at.o_lo_off = P->ctx.lo; }
     FCK(fdm_op_attention(&at, stream));
     FCK(need(P, lname(l, "self_attn.out_proj.bias"), d, &b));
     g = gemm_op(P, P->ctx, P->wt[lname(l, "self_attn.out_proj.weight")], R, d, d);
@@ -897,11 +896,11 @@ int tune_tiles(fdm_plan* P, int force, void* stream) {
   const char* env = getenv("FDM_TUNE");
   if (P->tile_cache.count(key)) return FDM_OK;
   if (!P->tune_enabled || (env && !strcmp(env, "0"))) return FDM_OK;       // heuristic tiles, or the pinned set of FDM_TILE_OVERRIDE
-  if (!force && P->steps_seen[key] < 2000) return FDM_OK;
+  if (!force && (P->steps_seen[key] < 2000 || P->tune_failed_shapes.count(key))) return FDM_OK;     // (a failed request-path tune is not repeated per request)
   const std::map<std::string, int> before = P->tiles;
   const int rc = tune_tiles_impl(P, stream);
-  if (rc != FDM_OK) { P->tiles = before; (void)drop_programs(P, stream); }   // never leave a trial set behind
-  else store_save(P, P->tiles);
+  if (rc != FDM_OK) { P->tiles = before; (void)drop_programs(P, stream); if (!force) P->tune_failed_shapes.insert(key); }   // never leave a trial set behind
+  else { store_save(P, P->tiles); P->tune_failed_shapes.erase(key); }
   return rc;
 }
 
@@ -944,10 +943,8 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
     }
     return FDM_OK;
   };
-  std::vector<int> cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64, FDM_TILE_128x64_S3,
-                            FDM_TILE_128x128, FDM_TILE_80x128, FDM_TILE_64x128};
-  if (is_split(P->dtype)) cands = {FDM_TILE_64x64, FDM_TILE_64x64_S3, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64_S3, FDM_TILE_128x128, FDM_TILE_80x128, FDM_TILE_64x128};
-  else if (P->R >= 1024) { cands.push_back(FDM_TILE_256x128); cands.push_back(FDM_TILE_256x128_PP); }
+  std::vector<int> cands = {FDM_TILE_64x64, FDM_TILE_64x64_S2, FDM_TILE_32x64_S3, FDM_TILE_128x64, FDM_TILE_128x128, FDM_TILE_80x128, FDM_TILE_64x128};
+  if (!is_split(P->dtype) && P->R >= 1024) cands.push_back(FDM_TILE_256x128_PP);
   // Which of them are worth a stopwatch is decided by a wave-quantisation model first.  What bounds these GEMMs is the
   // bytes a CU pulls from L2 into LDS: a BM x BN tile costs (BM + BN) * K * bytes-per-element (x planes)
   // and the busiest CU runs ceil(tiles / 256) of them (the whole grid is resident, or queued behind, at <= 160 KB / ring per CU),
@@ -958,15 +955,12 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
   auto geo = [&](int tile) -> Geo {
     const bool sp = is_split(P->dtype);
     switch (tile) {
-      case FDM_TILE_64x64_S3: return {64, 64, 3};
       case FDM_TILE_64x64_S2: return {64, 64, 2};
       case FDM_TILE_32x64_S3: return {32, 64, 3};
       case FDM_TILE_128x64: return {128, 64, sp ? 3 : 4};
-      case FDM_TILE_128x64_S3: return {128, 64, 3};
       case FDM_TILE_128x128: return {128, 128, sp ? 2 : 3};
       case FDM_TILE_80x128: return {80, 128, sp ? 3 : 4};
       case FDM_TILE_64x128: return {64, 128, sp ? 3 : 4};
-      case FDM_TILE_256x128:
       case FDM_TILE_256x128_PP: return {256, 128, 3};
       default: return {64, 64, 4};
     }
@@ -992,16 +986,12 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
     // several ids to one kernel: compare what the ids launch)
     auto launched = [&](int tile) {
       if (!is_split(P->dtype)) return tile;
-      switch (tile) {
-        case FDM_TILE_128x64: return FDM_TILE_128x64_S3;
-        case FDM_TILE_256x128: case FDM_TILE_256x128_PP: return FDM_TILE_128x128;
-        default: return tile;
-      }
+      return tile == FDM_TILE_256x128_PP ? FDM_TILE_128x128 : tile;
     };
     const int heur = launched(fdm_gemm_heuristic_tile(&kv.second[0]));
     for (int tile : cands) {
       if (launched(tile) == heur) continue;
-      if (kv.second[0].ksplit > 1 && tile != FDM_TILE_64x64 && tile != FDM_TILE_64x64_S3 && tile != FDM_TILE_64x64_S2 && tile != FDM_TILE_32x64_S3) continue;   // K-sliced sites
+      if (kv.second[0].ksplit > 1 && tile != FDM_TILE_64x64 && tile != FDM_TILE_64x64_S2 && tile != FDM_TILE_32x64_S3) continue;   // K-sliced sites
       if (kv.second[0].sched_fuse && tile != FDM_TILE_256x128_PP && tile != FDM_TILE_64x64) continue;      // the scheduler-fused decoder has two forms: 64x64 and the ping-pong tile
       if (modelled_us(kv.second[0], tile) > 1.35 * best_model) continue;
       float t = 0.f;
@@ -1075,7 +1065,7 @@ extern "C" {
 
 int fdm_plan_create(const fdm_model_desc* desc, int B, int L, int cfg, int dtype, fdm_plan** out) {
   if (!desc || !out) return fail(FDM_ERR_ARG, "plan_create: null argument");
-  if (dtype < FDM_F32 || dtype > FDM_BF16X3) return fail(FDM_ERR_ARG, "plan_create: bad dtype %d", dtype);
+  if (dtype < FDM_F32 || dtype > FDM_F16X3) return fail(FDM_ERR_ARG, "plan_create: bad dtype %d", dtype);
   const fdm_model_desc& m = *desc;
   if (m.d <= 0 || m.n_head <= 0 || m.d % m.n_head || m.n_layers <= 0 || m.ffn <= 0 || m.G * m.c != m.d || m.pair <= 0 || m.max_len <= 0)
     return fail(FDM_ERR_SHAPE, "plan_create: inconsistent model geometry (d %d, heads %d, G*c %d)", m.d, m.n_head, m.G * m.c);
@@ -1331,7 +1321,7 @@ int fdm_plan_get(fdm_plan* P, const char* key, long long* out) {
   else if (k == "ksplit.out") *out = P->ksplit_out;
   else if (k == "ksplit.ffn2") *out = P->ksplit_ffn2;
   else if (k == "tuned") *out = P->tile_cache.count(shape_key(P)) ? 1 : 0;
-  else if (k == "needs_tune") { const std::string sk = shape_key(P); *out = (!P->tile_cache.count(sk) && P->tune_enabled && P->steps_seen.count(sk) && P->steps_seen[sk] >= 2000) ? 1 : 0; }
+  else if (k == "needs_tune") { const std::string sk = shape_key(P); *out = (!P->tile_cache.count(sk) && P->tune_enabled && P->steps_seen.count(sk) && P->steps_seen[sk] >= 2000 && !P->tune_failed_shapes.count(sk)) ? 1 : 0; }
   else if (k == "tune_failed") *out = P->tune_failed;
   else if (k.rfind("tile.", 0) == 0) { auto it = P->tiles.find(k.substr(5)); *out = it == P->tiles.end() ? 0 : it->second; }
   else return fail(FDM_ERR_ARG, "plan_get: unknown key '%s'", key);
@@ -1350,7 +1340,6 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
   if (k == "ksplit.out" || k == "ksplit.ffn2") {      // K slices of the out-proj / FFN2 GEMMs (1 = none); tuned tiles of other split factors no longer apply
     const int kt = (k == "ksplit.out" ? P->m.d : P->m.ffn) / (P->dtype == FDM_F32 ? 32 : 64);
     if (value < 1 || value > 4 || kt % value) return fail(FDM_ERR_ARG, "plan_set: %s = %lld must be 1..4 and divide the %d k-tiles", key, value, kt);
-    if (P->dtype == FDM_BF16X3 && value > 1) return fail(FDM_ERR_ARG, "plan_set: %s is not offered for the bf16x3 comparison kind", key);
     int& cur = k == "ksplit.out" ? P->ksplit_out : P->ksplit_ffn2;
     if (cur == (int)value) return FDM_OK;
     cur = (int)value;
@@ -1358,7 +1347,7 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
     return drop_programs(P, nullptr);
   }
   if (k == "untune") {      // forget the tuned tiles of every shape (tests)
-    P->tile_cache.clear(); P->steps_seen.clear(); P->tiles.clear();
+    P->tile_cache.clear(); P->steps_seen.clear(); P->tiles.clear(); P->tune_failed_shapes.clear();
     return drop_programs(P, nullptr);
   }
   if (k.rfind("tile.", 0) == 0) {

@@ -7,8 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FDM_LIB_PATH: load another build of the same library (the AddressSanitizer host build, csrc `make asan`)
 LIB_PATH = os.environ.get("FDM_LIB_PATH") or os.path.join(_HERE, "libfdm_hip.so")
 
-F32, BF16, F16X3, BF16X3 = 0, 1, 2, 3      # include/fdm_hip.h FDM_*: operand kinds (the last two are split plane pairs)
-DTYPE_NAMES = {"f32": F32, "bf16": BF16, "f16x3": F16X3, "bf16x3": BF16X3}
+F32, BF16, F16X3 = 0, 1, 2      # include/fdm_hip.h FDM_*: operand kinds (the last one is a split plane pair)
+DTYPE_NAMES = {"f32": F32, "bf16": BF16, "f16x3": F16X3}
 ACT_NONE, ACT_RELU, ACT_MISH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02 = range(6)
 
 vp, ll, ci, cf = C.c_void_p, C.c_longlong, C.c_int, C.c_float
@@ -40,7 +40,9 @@ class GemmArgs(C.Structure):
                 ("ksplit", ci), ("ksplit_stride", ll), ("batch2", ci), ("a_batch_stride2", ll), ("out_batch_stride2", ll)]
 
 
-TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP, TILE_80x128, TILE_64x128 = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+# the eight tiles of include/fdm_hip.h, and the retired ids (accepted: they resolve to a live tile)
+TILE_AUTO, TILE_64x64, TILE_128x64, TILE_128x128, TILE_64x64_S2, TILE_32x64_S3, TILE_256x128_PP, TILE_80x128, TILE_64x128 = 0, 1, 2, 3, 8, 9, 10, 11, 12
+TILE_96x128, TILE_256x128, TILE_64x64_S3, TILE_128x64_S3 = 4, 5, 6, 7
 
 
 class ModelDesc(C.Structure):
@@ -111,8 +113,6 @@ SYMBOLS = {
     "fdm_prog_instantiate": (ci, [vp, vp]),
     "fdm_prog_replay": (ci, [vp, ci, vp]),
     "fdm_prog_num_ops": (ci, [vp]),
-    "fdm_prog_set_lane": (ci, [vp, ci]),
-    "fdm_prog_run_lanes": (ci, [vp, ci, vp]),
     "fdm_model_preset": (ci, [C.c_char_p, C.POINTER(ModelDesc)]),
     "fdm_plan_create": (ci, [C.POINTER(ModelDesc), ci, ci, ci, ci, C.POINTER(vp)]),
     "fdm_plan_reserve": (ci, [vp, ci, ci, ci]),
@@ -145,6 +145,7 @@ SYMBOLS = {
 }
 
 _lib = None
+LIB_VERSION = 105      # include/fdm_hip.h as this binding mirrors it (fdm_version()): struct layouts AND entry-point signatures
 
 
 class FdmError(RuntimeError):
@@ -163,6 +164,11 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        # a signature changed in place under an old symbol name would corrupt arguments silently: the build must be the one this
+        # binding was written for
+        if l.fdm_version() != LIB_VERSION:
+            raise FdmError(f"{LIB_PATH}: fdm_version() = {l.fdm_version()}, this binding is for {LIB_VERSION}: rebuild the library "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
         # the ctypes mirrors above must be the structs this build was compiled with (a stale .so or a header edit that
         # missed this file would otherwise corrupt arguments silently)
         for cname, mirror in STRUCTS.items():

@@ -186,8 +186,8 @@ class DenoiserPlan:
 
     # ------------------------------------------------------------------------------------------
     def tune(self):
-        """Tune the GEMM tiles for the prepared shape now (plan-time work; otherwise prepare() does it for a shape that
-        sampling calls have already run 2000 steps at -- never inside a sampling call)."""
+        """Tune the GEMM tiles for the prepared shape now (plan-time work).  Nothing else tunes: get("needs_tune") says when a
+        shape has run 2000 steps untuned; only a caller that set "tune_lazy" lets a sampling call tune (once per shape)."""
         with torch.cuda.device(self.device):
             check(lib().fdm_plan_tune(self.h, _stream()))
 

@@ -32,7 +32,7 @@ from .vq import VQPlan
 
 def compute_dtype(name=None):
     """Arithmetic mode of the HIP path: "fp32" (default; exact fp32 MFMA), "f16x3" (split-fp16 operands on the 16-bit matrix
-    cores: same 1e-4 contract, ~1.6x the frames/s), "bf16" (throughput mode, BASELINE.json configs[1]), "bf16x3" (comparison)."""
+    cores: same 1e-4 contract, ~1.6x the frames/s), "bf16" (throughput mode, BASELINE.json configs[1])."""
     name = (name or os.environ.get("FDM_AMD_DTYPE", "fp32")).lower()
     name = {"fp32": "f32", "float32": "f32", "bfloat16": "bf16"}.get(name, name)
     if name not in DTYPE_NAMES:
@@ -49,7 +49,7 @@ def _side_dtype(dt):
 
 def _audio_dtype(dt):
     """The audio encoders follow the step program's mode where they have it: fp32, bf16, or f16x3 (split-fp16 transformer layers
-    behind an fp32 conv front: inside the 1e-4 contract at 0.57x the fp32 encoder's time); bf16x3 falls back to fp32."""
+    and conv front: inside the 1e-4 contract at about half the fp32 encoder's time)."""
     return dt if dt in (F32, BF16, F16X3) else F32
 
 

@@ -8,12 +8,12 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, BF16X3, F16X3, F32,
+from ._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F16X3, F32,
                    AttnArgs, GemmArgs, LnArgs, SchedArgs, check, lib)
 
 
 class Split:
-    """A split-precision GEMM operand (include/fdm_hip.h, FDM_F16X3 / FDM_BF16X3): planes[0] = hi, planes[1] = lo of a
+    """A split-precision GEMM operand (include/fdm_hip.h, FDM_F16X3): planes[0] = hi, planes[1] = lo of a
     [rows, cols] matrix held in one [2, rows, cols] 16-bit tensor.  Slicing rows ([r0:]) keeps the plane distance."""
 
     def __init__(self, planes, code, row0=0, col0=0):
@@ -45,7 +45,7 @@ class Split:
 
     def float(self):
         """hi + lo / SCALE as fp32 (tests)."""
-        sc = 2048.0 if self.code == F16X3 else 1.0
+        sc = 2048.0
         return (self.planes[0].float() + self.planes[1].float() / sc)[self.row0:]
 
 
@@ -72,11 +72,11 @@ def stream():
 
 def tdtype(code):
     """torch dtype of the elements of operand kind `code` (split kinds: of each plane)."""
-    return {BF16: torch.bfloat16, BF16X3: torch.bfloat16, F16X3: torch.float16}.get(code, torch.float32)
+    return {BF16: torch.bfloat16, F16X3: torch.float16}.get(code, torch.float32)
 
 
 def is_split(code):
-    return code in (F16X3, BF16X3)
+    return code == F16X3
 
 
 def code_of(t):
@@ -283,10 +283,6 @@ class Program:
             check(rc)
         return False
 
-    def lane(self, i):
-        """Subsequent ops belong to independent chain i (a parallel branch of the captured graph)."""
-        check(lib().fdm_prog_set_lane(self.h, i))
-
     def hold(self, *tensors):
         self.keep.extend(tensors)
 
@@ -299,9 +295,6 @@ class Program:
 
     def instantiate(self):
         check(lib().fdm_prog_instantiate(self.h, stream()))
-
-    def run_lanes(self, n=1):
-        check(lib().fdm_prog_run_lanes(self.h, n, stream()))
 
     def replay(self, n=1):
         check(lib().fdm_prog_replay(self.h, n, stream()))

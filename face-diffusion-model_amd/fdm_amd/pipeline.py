@@ -72,11 +72,11 @@ def build_models(preset="vocaset", feature_dim=None, device="cuda:0", stage1=Non
 
 
 def _clip_x_T(shape, S, seed):
-    """DDPM start of a condition-batched call: one x_T per CLIP from the seed, shared by its S conditions (None for S = 1: the
-    sampler draws it, as before)."""
-    if S <= 1:
-        return None
-    return torch.randn(shape, generator=torch.Generator(device="cpu").manual_seed(seed)).repeat_interleave(S, dim=0)
+    """DDPM start of a sampling call: one x_T per CLIP from a CPU generator seeded with `seed` (the DDIM branch draws it the
+    same way), shared by the clip's S conditions -- so `seed=` reproduces a call, and the sequential S = 1 calls of a style loop
+    start where the batched call starts."""
+    x = torch.randn(shape, generator=torch.Generator(device="cpu").manual_seed(seed))
+    return x.repeat_interleave(S, dim=0) if S > 1 else x
 
 
 @torch.no_grad()
@@ -87,11 +87,12 @@ def animate(diffusion, autoencoder, audio, template=None, id_one_hot=None, emoti
     id_one_hot [B*S, n_style] (and emotion_one_hot [B*S, n_emo]) with S > 1 animates every clip under S conditions in ONE
     sampling call -- the reference sampler's style loop (samples/sample_diffusion_vocaset.py:71-83) batched: the audio
     encoder and the audio tables run once per clip, the S conditions ride the same step program.  Returns [B*S, L, V3] in
-    (clip, condition) order; every condition of a clip starts from the clip's x_T (what S sequential calls with the same
-    seed do), so the DDIM results (eta = 0: x_T is the only random input) are bit-identical to the sequential loop's.  On the
-    DDPM paths (S > 1) the conditions share the clip's x_T too, but the per-step noise is keyed by the ROW (clip * S + condition):
-    every condition draws its own stream, as the reference's S sequential calls do with a running generator -- equal in
-    distribution to the sequential loop, not bit for bit."""
+    (clip, condition) order.  x_T is drawn per CLIP from a CPU generator seeded with `seed` on every path (S = 1 too), so a call is
+    reproducible from its seed and every condition of a clip starts from the clip's x_T -- what S sequential calls with the same
+    seed do.  DDIM (eta = 0: x_T is the only random input): bit-identical to the sequential loop.  DDPM: the per-step noise is
+    Philox keyed by (seed, ROW = clip * S + condition, step), so a sequential call (row 0) draws the stream of the batched call's
+    row 0 only: the other conditions differ from their sequential calls by that stream -- equal in distribution (the reference's
+    sequential calls draw from one running generator), not bit for bit."""
     model = diffusion.denoise_fn.model if isinstance(diffusion.denoise_fn, ClassifierFreeSampleModel) else diffusion.denoise_fn
     p = model.preset
     audio = torch.as_tensor(audio, dtype=torch.float32, device=device)

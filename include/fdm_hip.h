@@ -40,11 +40,10 @@ extern "C" {
  * ELEMENTS after the hi plane, and the product evaluated as hi.hi + (hi.lo + lo.hi) / S in three passes of the 16-bit
  * MFMA with fp32 accumulation.  FDM_F16X3: fp16 planes, S = 2^11 (22 significant bits per operand: fp32-class results,
  * the mode that meets the 1e-4 contract on the 16-bit matrix cores; |x| is clamped to 65504); its QKV projection writes Q and
- * the packed K / V as plane pairs too and attention runs split (fdm_attn_args).  FDM_BF16X3: bf16 planes, S = 1 (16 bits per
- * operand; ~5e-5 per denoiser call -- kept for comparison); its QKV projection writes fp32 Q / packed K / V and attention
- * runs in fp32.  Every producer of a GEMM input writes the plane pair. */
+ * the packed K / V as plane pairs too and attention runs split (fdm_attn_args).  Every producer of a GEMM input writes the plane
+ * pair.  (A bf16-plane split -- 16 bits per operand, ~5e-5 per denoiser call, outside the contract over chains -- was built and
+ * measured in rounds 2-4 as kind 3 and is no longer part of the library: tools/sim_split_precision.py) */
 #define FDM_F16X3 2
-#define FDM_BF16X3 3
 
 #define FDM_ACT_NONE 0
 #define FDM_ACT_RELU 1       /* nn.TransformerDecoderLayer default activation, models/fdm_vocaset.py:45 */
@@ -112,8 +111,7 @@ typedef struct fdm_gemm_args {
   const void* W; long long ldw; long long w_batch_stride;
   int M, N, K, batch;
   int dtype;                      /* FDM_F32 | FDM_BF16: type of A, W, out_t, out_kp, out_vp;
-                                     FDM_F16X3: A, W, out_t, out_kp, out_vp are fp16 plane pairs;
-                                     FDM_BF16X3: A, W, out_t are bf16 plane pairs, out_kp / out_vp fp32 */
+                                     FDM_F16X3: A, W, out_t, out_kp, out_vp are fp16 plane pairs */
   const float* bias; long long bias_batch_stride;
   int act;
   const float* resid; long long ldr; int resid_row_mod;
@@ -150,7 +148,7 @@ typedef struct fdm_gemm_args {
    * N % 64 == 0, ldo_f32 == ldr == N, 16-byte aligned pointers; sched.x0 / x0u / x / x_out / x_out_t / arrive unused. */
   int sched_fuse;
   fdm_sched_args sched;
-  /* split operand kinds (dtype FDM_F16X3 / FDM_BF16X3): elements between the hi and lo planes of A, W and out_t */
+  /* split operand kind (dtype FDM_F16X3): elements between the hi and lo planes of A, W and out_t */
   long long a_lo_off, w_lo_off, out_t_lo_off;
   long long kv_lo_off;            /* FDM_F16X3 with out_kp / out_vp: elements between the hi and lo planes of the packed buffers */
   /* --- split K (round 5): ksplit = S > 1 runs S workgroups per output tile (blockIdx.z = slice s); slice s accumulates the
@@ -159,32 +157,40 @@ typedef struct fdm_gemm_args {
    * (fdm_ln_args.x_planes): no atomics, no extra launch, deterministic.  A workgroup's dependent k chain is 1/S as long and S
    * chains share a CU.  Results depend on S (the k order changes), never on `tile`.  Needs batch <= 1, act NONE, out_f32 as the
    * only output, dense vectorisable rows (N % 64 == 0), (K / 64 [16-bit kinds] or K / 32 [fp32]) % S == 0, S <= 4 (8 measured: no further gain); tiles: the
-   * 64x64 family (FDM_TILE_64x64 / _S3 / _S2) and FDM_TILE_32x64_S3. */
+   * 64-column tiles FDM_TILE_64x64, FDM_TILE_64x64_S2 and FDM_TILE_32x64_S3. */
   int ksplit; long long ksplit_stride;
   /* --- second batch level (round 5): batch2 = C >= 1 runs C x batch problems in one launch, z = (c, g): A advances by
    * a_batch_stride per g and by a_batch_stride2 per c, outputs and resid by out_batch_stride (a column offset) per g and by
    * out_batch_stride2 (elements: a row offset) per c; W and bias depend on g alone.  This is a grouped Conv1d over C clips
    * (HuBERT's positional conv: g = channel group, c = clip).  When batch % 8 == 0 the workgroups are dealt so that XCD x serves
    * the groups [x batch / 8, (x + 1) batch / 8) only, group-major: each L2 streams its 1 / 8 of W once for all clips and row
-   * tiles.  Tiles: FDM_TILE_64x64 / _S3 and FDM_TILE_128x64 / _S3; no ksplit, no LayerNorm folds, no packed K / V, no fused scheduler. */
+   * tiles.  Tiles: FDM_TILE_64x64, FDM_TILE_64x64_S2 and FDM_TILE_128x64; no ksplit, no LayerNorm folds, no packed K / V, no fused scheduler. */
   int batch2; long long a_batch_stride2, out_batch_stride2;
 } fdm_gemm_args;
 #define FDM_TILE_AUTO 0
-#define FDM_TILE_64x64 1
-#define FDM_TILE_128x64 2
+/* Eight tiles (round 5; eleven before).  Every tile accumulates k in the same order: the choice changes speed, never results. */
+#define FDM_TILE_64x64 1       /* 8 waves, 4-stage ring (64 KB; split kinds 128 KB) */
+#define FDM_TILE_128x64 2      /* 4-stage ring while the launch is one round (<= 256 workgroups), else 3-stage (72 KB: two workgroups per CU);
+                                  split kinds: 3-stage (144 KB) */
 #define FDM_TILE_128x128 3
-#define FDM_TILE_96x128 4      /* retired (round 4: never picked by the tuner on any shape): resolves to 128x128 */
-#define FDM_TILE_256x128 5
-#define FDM_TILE_64x64_S3 6   /* 64x64 with a 3-stage ring (three workgroups per CU) */
-#define FDM_TILE_128x64_S3 7  /* 128x64 with a 3-stage ring (two workgroups per CU) */
-#define FDM_TILE_64x64_S2 8   /* 64x64 with a 2-stage ring (four workgroups per CU) */
-#define FDM_TILE_32x64_S3 9   /* 32x64 on 4 waves, 3-stage ring: twice the workgroups of 64x64 for few-hundred-row GEMMs */
-#define FDM_TILE_256x128_PP 10 /* 256x128, two wave groups half a period apart (one computes while the other loads): large M */
+#define FDM_TILE_64x64_S2 8    /* 64x64 with a 2-stage ring (four workgroups per CU; split kinds two) */
+#define FDM_TILE_32x64_S3 9    /* 32x64 on 4 waves, 3-stage ring: twice the workgroups of 64x64 for few-hundred-row GEMMs */
+#define FDM_TILE_256x128_PP 10 /* 256x128, two wave groups half a period apart (one computes while the other loads): large M; split kinds: 128x128 */
 #define FDM_TILE_80x128 11     /* 80x128: ten row tiles for 800 rows -> 240 workgroups at N = 3072 (the QKV projection of four 200-frame clips) */
 #define FDM_TILE_64x128 12     /* 64x128: 13 row tiles for 800 rows -> 208 workgroups at N = 2048 in one round (FFN1 in the split modes) */
+/* retired ids (accepted, resolve to a live tile; no heuristic rule returns them and the tuner does not time them):
+ *   4  96x128 (round 4: never picked on 66 shapes)                         -> 128x128
+ *   5  256x128 on the lockstep loop (round 5: 29.9 us against 29.4 for the ping-pong loop on its one heuristic site) -> 256x128_PP
+ *   6  64x64 on a 3-stage ring (round 5: 3 tuner picks on 66 shapes, no heuristic rule) -> 64x64
+ *   7  128x64 on a 3-stage ring (round 5: the ring depth follows the grid, see 128x64)  -> 128x64 */
+#define FDM_TILE_96x128 4
+#define FDM_TILE_256x128 5
+#define FDM_TILE_64x64_S3 6
+#define FDM_TILE_128x64_S3 7
 #define FDM_TILE_MAX 12
 /* or-ed into `tile`: run the general (edge-handling) kernel even where a specialised one would do -- the two must agree bit for
- * bit (tests/test_ops_gpu.py); not a tuning knob */
+ * bit (tests/test_ops_gpu.py); not a tuning knob.  Honoured by every tile including the ping-pong one; the scheduler-fused latent
+ * decoder (sched_fuse) has lean kernels only and ignores it. */
 #define FDM_TILE_GENERAL 0x100
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 /* The FDM_TILE_* value a launch of *a with tile = 0 resolves to (the library heuristic on M, N, K, batch and the operand kind;
@@ -218,7 +224,7 @@ typedef struct fdm_attn_args {
   int causal;
   const float* slopes;   /* [H] device floats or NULL */
   int period;
-  /* o_split = FDM_F16X3 / FDM_BF16X3 (with dtype FDM_F32): O is written as a split plane pair (the next GEMM's input),
+  /* o_split = FDM_F16X3 (with dtype FDM_F32): O is written as a split plane pair (the next GEMM's input),
    * lo plane o_lo_off elements after the hi plane; 0 = O has the dtype of Q */
   int o_split; long long o_lo_off;
   /* dtype FDM_F16X3: Q, Kp, Vp and O are fp16 plane pairs (the 16-bit packed layout, per plane); both products run as three
@@ -339,15 +345,6 @@ int fdm_prog_run(fdm_prog* p, void* stream);                 /* eager: launch ev
 int fdm_prog_instantiate(fdm_prog* p, void* stream);         /* capture into a hipGraph */
 int fdm_prog_replay(fdm_prog* p, int n, void* stream);       /* launch the graph n times */
 int fdm_prog_num_ops(fdm_prog* p);
-/* While recording: tag subsequent ops with an independent lane (chain).  Clips are independent, so the
- * per-clip-group chains of a step carry no mutual dependencies; fdm_prog_instantiate captures one
- * hipGraph per lane and fdm_prog_replay launches them on per-lane internal streams (forked from and
- * joined into the caller's stream once per replay call), so the chains' kernels overlap on the
- * device.  fdm_prog_run executes all ops in program order on the caller's stream. */
-int fdm_prog_set_lane(fdm_prog* p, int lane);
-/* Run every lane's ops eagerly n times (no hipGraph), each lane on its own internal stream fed by its own
- * host thread; joined into `stream` at the end. */
-int fdm_prog_run_lanes(fdm_prog* p, int n, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Plan layer.  A plan owns device copies of the model's weights, the tables derived from them,
@@ -372,7 +369,7 @@ int fdm_model_preset(const char* name, fdm_model_desc* out);
 
 typedef struct fdm_plan fdm_plan;
 /* Workspaces for up to B clips x L latent frames (x2 rows when cfg != 0: cond + uncond rows in one set of launches).
- * dtype: FDM_F32 | FDM_BF16 | FDM_F16X3 | FDM_BF16X3 = the arithmetic mode of the step program. */
+ * dtype: FDM_F32 | FDM_BF16 | FDM_F16X3 = the arithmetic mode of the step program. */
 int fdm_plan_create(const fdm_model_desc* desc, int B, int L, int cfg, int dtype, fdm_plan** out);
 int fdm_plan_reserve(fdm_plan* p, int B, int L, int cfg);           /* grow the workspaces (allocates; drops recorded programs) */
 int fdm_plan_destroy(fdm_plan* p);

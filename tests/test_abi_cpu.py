@@ -139,7 +139,7 @@ def test_plan_layer_argument_validation_without_device():
     assert l.fdm_plan_destroy(None) == 0
     h = C.c_void_p()
     assert l.fdm_hubert_create(2, 0, 0, C.byref(h)) == -1 and b"kind" in l.fdm_last_error()
-    assert l.fdm_hubert_create(0, 0, _lib.BF16X3, C.byref(h)) == -1                      # audio encoders: fp32 / bf16 / f16x3 (split-fp16 layers)
+    assert l.fdm_hubert_create(0, 0, 3, C.byref(h)) == -1                      # audio encoders: fp32 / bf16 / f16x3 (split-fp16 layers)
     assert l.fdm_hubert_create(0, 0, _lib.F16X3, C.byref(h)) == 0 and l.fdm_hubert_destroy(h) == 0
     assert l.fdm_hubert_create(1, 0, 0, C.byref(h)) == 0                                 # creation itself needs no device
     assert l.fdm_hubert_set_weights(h, b"encoder.layer_norm.weight", None, 768, None) == -1
@@ -185,14 +185,14 @@ def test_tile_heuristic_is_a_pure_function_of_the_shape():
     assert tile(B, 100, 1024, 1024) == _lib.TILE_64x64 and tile(S, 100, 1024, 1024) == _lib.TILE_32x64_S3
     assert tile(S, 600, 3072, 1024) == _lib.TILE_64x64_S2 and tile(S, 800, 1024, 1024) == _lib.TILE_64x64
     assert tile(B, 1992, 2048, 1024) == _lib.TILE_128x128 and tile(S, 1992, 2048, 1024) == _lib.TILE_128x128      # 16 x 16 = 256 tiles
-    assert tile(B, 2400, 3072, 1024) == _lib.TILE_256x128                                                         # 10 x 24 = 240 tiles
-    assert tile(B, 1200, 1024, 1024) == _lib.TILE_128x64 and tile(B, 3000, 1024, 1024) == _lib.TILE_128x64_S3 and tile(B, 3200, 1024, 1024) == _lib.TILE_128x128
-    assert tile(S, 1200, 1024, 1024) == _lib.TILE_128x64_S3 and tile(S, 2400, 2048, 1024) == _lib.TILE_64x64
+    assert tile(B, 2400, 3072, 1024) == _lib.TILE_256x128_PP                                                         # 10 x 24 = 240 tiles
+    assert tile(B, 1200, 1024, 1024) == _lib.TILE_128x64 and tile(B, 3000, 1024, 1024) == _lib.TILE_128x64 and tile(B, 3200, 1024, 1024) == _lib.TILE_128x128
+    assert tile(S, 1200, 1024, 1024) == _lib.TILE_128x64 and tile(S, 2400, 2048, 1024) == _lib.TILE_64x64
     assert tile(B, 1200, 512, 512) == _lib.TILE_64x64                   # MEAD's short-K sites stay on the resident 64x64 grid
     assert tile(F, 1992, 2048, 1024) == _lib.TILE_64x64 and tile(F, 1200, 1024, 1024) == _lib.TILE_64x64
-    assert tile(B, 6400, 3072, 1024) == _lib.TILE_128x128 and tile(S, 6400, 1024, 2048) == _lib.TILE_128x64_S3
+    assert tile(B, 6400, 3072, 1024) == _lib.TILE_128x128 and tile(S, 6400, 1024, 2048) == _lib.TILE_128x64
     assert tile(B, 6400, 1024, 2048) == _lib.TILE_256x128_PP and tile(B, 3200, 2048, 1024) == _lib.TILE_256x128_PP      # thousands of rows: the ping-pong loop
     assert tile(B, 6400, 1024, 1024, sched_fuse=1) == _lib.TILE_256x128_PP and tile(F, 6400, 1024, 1024, sched_fuse=1) == _lib.TILE_64x64
     assert tile(B, 2400, 1024, 1024) == _lib.TILE_80x128                # 30 x 8 = 240 tiles
-    assert tile(B, 800, 1024, 1024, sched_fuse=1) == _lib.TILE_64x64 and tile(_lib.BF16X3, 1992, 2048, 1024) == _lib.TILE_64x64
+    assert tile(B, 800, 1024, 1024, sched_fuse=1) == _lib.TILE_64x64
     assert tile(B, 100, 1024, 1024, batch=8) == _lib.TILE_64x64

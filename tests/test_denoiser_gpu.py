@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from fdm_amd.denoiser import DenoiserPlan  # noqa: E402
-from fdm_amd._lib import BF16, BF16X3, F16X3, F32  # noqa: E402
+from fdm_amd._lib import BF16, F16X3, F32  # noqa: E402
 from oracle import fdm_oracle as FO  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
@@ -59,13 +59,14 @@ def test_single_step_bf16_stated_tolerance(golden, preset):
         assert mad(out[0], g[f"x0_L{L}_t{t}"]) < TOLBF, (preset, L, t)
 
 
-def test_bf16x3_split_is_short_of_the_contract_f16x3_is_not(golden):
-    """Why the split mode uses fp16 planes: with bf16 planes (8 bits each, 16 per operand) one full-size denoiser call is
-    already ~5e-5 from the reference (a 50-step chain exceeds 1e-4), with fp16 planes (11 + 11 bits) it is at the fp32
-    kernel's own distance."""
+def test_f16x3_split_sits_at_the_fp32_kernels_distance(golden):
+    """Why the split mode uses fp16 planes: 11 + 11 bits per operand put a full-size denoiser call at the fp32 MFMA kernel's own
+    distance from the reference.  (bf16 planes -- 8 + 8 bits -- were built and measured in rounds 2-4: 4.9e-5 per call, > 1e-4
+    over a 50-step chain; tools/sim_split_precision.py predicted both before any kernel was written.  That kind is no longer part
+    of the library.)"""
     g = golden("fdm_step_vocaset")
     err = {}
-    for dt in (F32, F16X3, BF16X3):
+    for dt in (F32, F16X3):
         plan, _ = plan_for("vocaset", dt)
         e = 0.0
         for (L, t) in g["cases"].tolist():
@@ -73,9 +74,8 @@ def test_bf16x3_split_is_short_of_the_contract_f16x3_is_not(golden):
             plan.prepare(inp["hub"], inp["style"], L=L)
             e = max(e, mad(plan.denoise(inp["x"].to(DEV), t)[0], g[f"x0_L{L}_t{t}"]))
         err[dt] = e
-    print(f"max-abs vs reference goldens: f32 {err[F32]:.2e}  f16x3 {err[F16X3]:.2e}  bf16x3 {err[BF16X3]:.2e}")
+    print(f"max-abs vs reference goldens: f32 {err[F32]:.2e}  f16x3 {err[F16X3]:.2e}")
     assert err[F16X3] < 3 * max(err[F32], 5e-6) and err[F16X3] < TOL32
-    assert err[BF16X3] < 1e-3 and err[BF16X3] > 2 * err[F16X3]
 
 
 @pytest.mark.parametrize("dtype", PARITY_MODES)

@@ -54,7 +54,7 @@ def test_hubert_bf16_stated_tolerance(golden):
 
 
 def test_audio_encoders_in_the_contract_mode_vs_golden(golden):
-    """FDM_F16X3 audio encoders (split-fp16 transformer layers behind an fp32 conv front, csrc/encoders.hip): inside the 1e-4
+    """FDM_F16X3 audio encoders (split-fp16 operands from conv 0 to the last transformer layer, csrc/encoders.hip): inside the 1e-4
     contract against the same reference goldens as the fp32 encoders -- HuBERT-large 2 / 24 layers, 2 s and 10 s; wav2vec2-base
     (post-LN, d = 768) -- and a batch equals its clips run one at a time."""
     from fdm_amd._lib import F16X3

@@ -39,7 +39,7 @@ def one(tile, dst=out):
 per_clip(0, ref); torch.cuda.synchronize()
 fl = 2.0 * C * T * D * KW * dg
 print(f"== positional conv {mode}: {C} clips x {T} frames, D = {D} ({G} groups of {dg}), {fl / 1e9:.1f} GFLOP ==")
-for name, tile in (("64x64/4", TILE_64x64), ("64x64/3", TILE_64x64_S3), ("128x64/4", TILE_128x64), ("128x64/3", TILE_128x64_S3)):
+for name, tile in (("64x64", TILE_64x64), ("64x64/2", TILE_64x64_S2), ("128x64", TILE_128x64)):      # (profiles/r5_posconv/ also lists the 3-stage rings of commit 56559b2, since retired)
     a = timeit(lambda: per_clip(tile), n_rec=1, reps=20)
     out.zero_(); one(tile); torch.cuda.synchronize()
     b = timeit(lambda: one(tile), n_rec=1, reps=20)

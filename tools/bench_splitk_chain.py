@@ -23,7 +23,7 @@ code = {'bf16': BF16, 'f16x3': F16X3, 'f32': F32}[mode]
 B, L, d, H, ffn = 4, int(sys.argv[2]) if len(sys.argv) > 2 else 200, 1024, 8, 2048
 M, hd = B * L, 128
 torch.manual_seed(0)
-TN = {TILE_64x64: "64x64/4", TILE_64x64_S3: "64x64/3", TILE_64x64_S2: "64x64/2", TILE_32x64_S3: "32x64/3"}
+TN = {TILE_64x64: "64x64/4", TILE_64x64_S2: "64x64/2", TILE_32x64_S3: "32x64/3"}      # (the 3-stage 64x64 ring of the committed runs -- commit 7a4671f -- is retired)
 
 
 def opnd(rows, cols):
@@ -70,7 +70,7 @@ def reset():
 
 ref = None
 print(f"== {mode}, {M} rows ==")
-for S, tile in ((1, TILE_64x64), (2, TILE_64x64), (2, TILE_64x64_S3), (2, TILE_64x64_S2), (4, TILE_64x64), (4, TILE_64x64_S2), (2, TILE_32x64_S3), (4, TILE_32x64_S3)):
+for S, tile in ((1, TILE_64x64), (2, TILE_64x64), (2, TILE_64x64_S2), (4, TILE_64x64), (4, TILE_64x64_S2), (2, TILE_32x64_S3), (4, TILE_32x64_S3)):
     reset(); chain_a(S, tile); torch.cuda.synchronize(); out = h.clone()
     reset(); chain_a(S, tile); torch.cuda.synchronize(); det = bool(torch.equal(out, h))
     if ref is None: ref = out
@@ -113,7 +113,6 @@ def layers(So, to, Sf, tf):
 variants = [(1, TILE_64x64, 1, TILE_64x64),
             (2, TILE_64x64, 1, TILE_64x64), (2, TILE_64x64_S2, 1, TILE_64x64), (4, TILE_64x64_S2, 1, TILE_64x64),
             (1, TILE_64x64, 2, TILE_64x64), (1, TILE_64x64, 2, TILE_64x64_S2), (1, TILE_64x64, 4, TILE_64x64), (1, TILE_64x64, 4, TILE_64x64_S2),
-            (1, TILE_64x64, 4, TILE_64x64_S3),
             (2, TILE_64x64, 2, TILE_64x64), (2, TILE_64x64, 4, TILE_64x64), (2, TILE_64x64, 4, TILE_64x64_S2), (2, TILE_64x64_S2, 4, TILE_64x64_S2),
             (2, TILE_32x64_S3, 4, TILE_32x64_S3), (4, TILE_64x64_S2, 4, TILE_64x64_S2),
             (4, TILE_32x64_S3, 4, TILE_32x64_S3), (4, TILE_32x64_S3, 8, TILE_32x64_S3), (2, TILE_32x64_S3, 8, TILE_32x64_S3), (8, TILE_32x64_S3, 8, TILE_32x64_S3),

@@ -36,7 +36,7 @@ def out_t(M, N, dt):
 g = torch.Generator().manual_seed(5)
 GEN = 0x100 if (len(sys.argv) > 1 and sys.argv[1] == '1') else 0      # include/fdm_hip.h FDM_TILE_GENERAL
 for dt in (BF16, F32, F16X3):
-    for tile in (0 | GEN, 2 | GEN, 3 | GEN, 8 | GEN):
+    for tile in (0 | GEN, 2 | GEN, 3 | GEN, 8 | GEN, 10 | GEN):      # (10 = the ping-pong tile: its launcher honours FDM_TILE_GENERAL too)
         # plain / heavy, interior and edge shapes
         for (M, N, K, act) in ((800, 1024, 1024, ACT_NONE), (130, 2048, 512, ACT_RELU), (64, 1024, 1024, ACT_MISH), (77, 192, 256, ACT_RELU)):
             A, W = opnd(torch.randn(M, K, generator=g), dt), opnd(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
