@@ -156,7 +156,8 @@ def hbm_class_roofline(pm, rel, p, rows, dtype_name):
         gbs = b / (k["avg_us"] * 1e-6) / 1e9
         out.append({"kernel": "LayerNorm launches (fused LN1+LN2 with the folded cross-attention addend; LN3)", "launches_per_step": k["launches_per_step"],
                     "algorithmic_bytes_per_launch": int(b), "avg_us_profiled": k["avg_us"], "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4),
-                    "counter_bytes_per_launch": int((k.get("fetch_mb", 0) + k.get("write_mb", 0)) * 1024 * 1024) or None})
+                    "counter_bytes_per_launch": int((k.get("fetch_mb", 0) + k.get("write_mb", 0)) * 1024 * 1024) or None,
+                    "traffic_ratio": round((k.get("fetch_mb", 0) + k.get("write_mb", 0)) * 1024 * 1024 / b, 3) or None})      # counter / algorithmic bytes
     dec = [k for k in pm["kernels"] if "gemm" in k["kernel"] and "true, 1>" in k["kernel"].replace(" ", " ") and "false, true" in k["kernel"]]
     if dec:
         k = dec[0]
@@ -164,10 +165,13 @@ def hbm_class_roofline(pm, rel, p, rows, dtype_name):
         out.append({"kernel": "scheduler update in the latent decoder's GEMM epilogue", "launches_per_step": k["launches_per_step"],
                     "algorithmic_bytes_per_launch": int(b), "avg_us_profiled": k["avg_us"],
                     "achieved": round(b / (k["avg_us"] * 1e-6) / 1e9, 1), "frac": round(b / (k["avg_us"] * 1e-6) / 1e9 / 8000.0, 4),
+                    "counter_bytes_per_launch": int((k.get("fetch_mb", 0) + k.get("write_mb", 0)) * 1024 * 1024) or None,
+                    "traffic_ratio": None,       # (the launch's counters hold the GEMM's operand traffic too: no epilogue-only figure)
                     "note": "duration of the whole GEMM launch (the plain 64x64 GEMM of the same shape takes "
                             + str(next((q["avg_us"] for q in pm["kernels"] if "gemm" in q["kernel"] and "false, false, 1>" in q["kernel"] and q["grid"] == k["grid"]), None))
                             + " us): the update rides an MFMA-class kernel"})
-    return {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "counters_from": rel, "kernels": out} if out else None
+    return {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "counters_from": rel, "counters_commit": pm["summary"].get("commit"),
+            "counters_date": pm["summary"].get("date"), "kernels": out} if out else None
 
 
 PARITY_TOL = {"f32": 1e-4, "f16x3": 1e-4, "bf16": 0.15}     # the bars tests/test_denoiser_gpu.py states per mode
@@ -206,6 +210,8 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="skip the contract-mode leg and the parity legs (sweeps, profiles)")
     ap.add_argument("--contract-steps", type=int, default=5, help="timed sampling calls of the contract-mode (f16x3) leg")
     ap.add_argument("--profile-steps", type=int, default=0, help="profiling only: shorten the diffusion chain to this many steps")
+    ap.add_argument("--chain-steps", type=int, default=0, help="tests only: shorten the diffusion chain to this many steps, every stage of the call kept "
+                                                              "(audio encoder, quant, decode, gather)")
     ap.add_argument("--batch", type=int, default=0, help="clips per GPU instead of the configuration's (row-count sweeps, tests)")
     ap.add_argument("--broadcast-weights", action="store_true",
                     help="N > 1: rank 0's weights are broadcast to every rank (one flattened RCCL broadcast, outside the timed region) "
@@ -241,8 +247,8 @@ def main():
 
     preset, B, L, T, sampler, cfg = CONFIGS[a.config]
     S = CONDS.get(a.config, 1)              # style conditions per clip in one step program
-    if a.profile_steps:
-        T = a.profile_steps
+    if a.profile_steps or a.chain_steps:
+        T = a.profile_steps or a.chain_steps
     if a.batch:
         B = a.batch
     p = presets.get(preset)
@@ -326,8 +332,9 @@ def main():
             else:
                 hub_plan = HubertPlan(W.make_hubert_weights(24), 24, hub_dt, dev)
             vq_plan = VQPlan(preset, W.make_vq_weights(preset), side_dt, dev)
-            g = torch.Generator().manual_seed(100 + rank)
-            wav = (torch.randn(B, int(shipped[1] * 16000) if shipped else 160000, generator=g) * 0.1).to(dev)
+            # audio keyed by the GLOBAL clip index (like the Philox noise): a clip is the same clip on whichever rank it lands
+            n_wav = int(shipped[1] * 16000) if shipped else 160000
+            wav = (torch.cat([torch.randn(1, n_wav, generator=torch.Generator().manual_seed(100 + rank * B + b)) for b in range(B)]) * 0.1).to(dev)
         emo_b = emo                                          # [B*S] rows for the batched call (None where the preset has none)
         emo_clip = None if emo is None else emo[:B]          # one row per clip: the codebook slice of the EVQ quantiser
 
@@ -487,10 +494,11 @@ def main():
 
         def counters(leg):
             r = leg["roofline"]
-            r.update({"mfma_busy": None, "dominant_kernel": None, "counters_from": None, "counters_tiles": None, "counters_tiles_match": None})
+            r.update({"mfma_busy": None, "dominant_kernel": None, "counters_from": None, "counters_commit": None, "counters_date": None,
+                      "counters_tiles": None, "counters_tiles_match": None})
             if a.batch:
                 return
-            for rd in ("r4", "r3", "r2"):
+            for rd in ("r5", "r4", "r3", "r2"):
                 try:
                     rel = f"profiles/{rd}_pmc_{a.config}_{leg['dtype']}/summary.json"
                     pm = json.load(open(os.path.join(ROOT, rel)))
@@ -500,6 +508,7 @@ def main():
                     r["traffic"] = pm["summary"]["traffic_bytes_per_step"]
                     r["mfma_busy"] = pm["summary"]["mfma_busy_time_weighted"]
                     r["counters_from"] = rel
+                    r["counters_commit"], r["counters_date"] = pm["summary"].get("commit"), pm["summary"].get("date")      # build and day the profile was taken on
                     r["counters_tiles"] = prof_tiles
                     r["counters_tiles_match"] = prof_tiles == leg["gemm_tiles"]
                     leg["roofline_hbm"] = hbm_class_roofline(pm, rel, p, B * S * L * (2 if cfg else 1), leg["dtype"])
@@ -507,7 +516,13 @@ def main():
                     same_sites = all(prof_tiles.get(site, 0) == leg["gemm_tiles"].get(site, 0) for site in ("out", "ffn2"))
                     if ks and same_sites:
                         k = max(ks, key=lambda q: q["launches_per_step"] * q["avg_us"])
+                        # its own roofline entry: the kernel serves the out-proj (K = d) and FFN2 (K = ffn) sites, rows x d outputs each
+                        rows_k = B * S * L * (2 if cfg else 1)
+                        k_fl = 2.0 * rows_k * p.d * (p.d + p.ffn) / 2.0 if k["launches_per_step"] == 2 * p.n_layers else None
+                        k_ach = k_fl / (k["avg_us"] * 1e-6) / 1e12 if k_fl else None
                         r["dominant_kernel"] = {"name": k["kernel"], "launches_per_step": k["launches_per_step"], "avg_us_profiled": k["avg_us"],
+                                                "flops_per_launch": k_fl, "achieved": round(k_ach, 1) if k_ach else None, "unit": "TFLOP/s",
+                                                "frac": round(k_ach / PEAK[leg["dtype"]], 4) if k_ach else None,
                                                 "mfma_busy": k.get("mfma_busy"), "wave_cycles_waiting": k.get("wait"), "l2_hit": k.get("l2_hit"),
                                                 "fetch_mb": k.get("fetch_mb"), "write_mb": k.get("write_mb")}
                     return

@@ -103,6 +103,24 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     assert rec["parity"]["max_abs"] < 1e-4 and rec["parity"]["dtype"] == "f32"
     a, b = np.load(one), np.load(two)
     assert a.shape == b.shape == (2, 1600, 64) and np.array_equal(a, b)
+    # cfg5's gather: the end-to-end call (HuBERT-large -> tables -> a shortened chain -> quant -> decode) ends with the all-gather of
+    # [clips, 498, 15069] fp32 vertices -- 60 MB per rank here, 120 MB at the benched 4 clips per GPU -- not the 3 MB of latents above
+    common5 = [sys.executable, bench, "--config", "cfg5", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--headline-only", "--chain-steps", "6", "--dtype", "bf16"]
+    one5, two5 = str(tmp_path / "one5.npy"), str(tmp_path / "two5.npy")
+    r = subprocess.run(common5 + ["--gpus", "1", "--batch", "4", "--dump", one5], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   FDM_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(common5 + ["--gpus", "2", "--batch", "2", "--dump", two5], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=1200) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[0] + o[1] for o in outs)
+    rec = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["config"]["global_batch"] == 4
+    a, b = np.load(one5), np.load(two5)
+    assert a.shape == b.shape == (4, 498, 15069) and np.isfinite(a).all() and np.array_equal(a, b)
 
 
 @pytest.mark.parametrize("config", ["shipped_biwi", "shipped_vocaset"])

@@ -63,6 +63,38 @@ def test_two_rank_shard_and_gather(n_clips):
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == n_clips      # contiguous cover
 
 
+def _vertex_worker(rank, world, port, q):
+    """cfg5's collective at its benched size: every rank contributes [4, 498, 15069] fp32 vertices (120 MB)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, L, V3 = 4, 498, 15069
+        ramp = torch.arange(L * V3, dtype=torch.float32).reshape(L, V3) * 1e-6
+        local = torch.stack([ramp + float(rank * B + b) for b in range(B)])          # a function of the GLOBAL clip index
+        full = gather_clips(local, dist, sizes=[B] * world)                            # equal shards: no size exchange (bench.py)
+        ok = full.shape == (B * world, L, V3) and full.numel() * 4 == 120_069_792 * world
+        for i in range(B * world):
+            ok = ok and torch.equal(full[i], ramp + float(i))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_cfg5_sized_vertices():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_vertex_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res)
+
+
 def test_shard_range_properties():
     for n in (1, 4, 7, 32):
         for w in (1, 2, 4, 8):

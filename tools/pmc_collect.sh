@@ -29,5 +29,5 @@ pass fetch FETCH_SIZE TCC_HIT_sum
 pass write WRITE_SIZE TCC_MISS_sum TCC_EA0_RDREQ_DRAM_sum
 pass tcp TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum
 HEAD=$(cd $ROOT && git rev-parse --short HEAD 2>/dev/null || echo unknown)
-python3 $ROOT/tools/pmc_report.py derive $OUT $OUT/summary.json "{\"tag\": \"$TAG\", \"bench_args\": \"$BENCH_ARGS\", \"tiles\": \"${FDM_TILE_OVERRIDE:-tuned per run}\", \"steps_profiled\": $(live $OUT/trace.log)}"
+python3 $ROOT/tools/pmc_report.py derive $OUT $OUT/summary.json "{\"tag\": \"$TAG\", \"bench_args\": \"$BENCH_ARGS\", \"tiles\": \"${FDM_TILE_OVERRIDE:-tuned per run}\", \"steps_profiled\": $(live $OUT/trace.log), \"commit\": \"${FDM_COMMIT:-$HEAD}\", \"date\": \"$(date -u +%F)\"}"
 ls $OUT
