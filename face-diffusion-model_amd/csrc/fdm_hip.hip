@@ -128,7 +128,7 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if ((a->ln_colsum || a->rln_gamma) && !a->ln_stat_in) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding needs ln_stat_in");
   if (a->rln_gamma && (!a->rln_beta || !a->resid)) return fail(FDM_ERR_ARG, "gemm: rln_gamma needs rln_beta and resid");
   if ((a->stat_out || a->ln_stat_in) && (a->batch > 1 || a->out_batch_stride)) return fail(FDM_ERR_ARG, "gemm: LayerNorm folding is not batched");
-  if (a->tile < 0 || (a->tile & ~FDM_TILE_GENERAL) > FDM_TILE_MAX) return fail(FDM_ERR_ARG, "gemm: unknown tile %d", a->tile);
+  if (a->tile < 0 || (a->tile & FDM_TILE_ID_MASK) > FDM_TILE_MAX) return fail(FDM_ERR_ARG, "gemm: unknown tile %d", a->tile);
   if (a->sched_fuse) {
     const fdm_sched_args& sc = a->sched;
     if (sc.mode != 0 && sc.mode != 1) return fail(FDM_ERR_ARG, "gemm: fused scheduler supports mode 0 (DDPM) and 1 (DDIM)");
@@ -143,7 +143,7 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   }
   if (a->ksplit < 0 || a->ksplit > 4) return fail(FDM_ERR_ARG, "gemm: ksplit %d outside 0..4", a->ksplit);
   if (a->ksplit > 1) {
-    const int tl = a->tile & ~FDM_TILE_GENERAL;
+    const int tl = a->tile & FDM_TILE_ID_MASK;
     if (a->batch > 1 || a->out_batch_stride || a->act != FDM_ACT_NONE || !a->out_f32 || a->out_t || a->out_kp || a->out_vp || a->stat_out || a->ln_stat_in ||
         a->sched_fuse || a->resid_row_mod || (a->tile & FDM_TILE_GENERAL))
       return fail(FDM_ERR_ARG, "gemm: ksplit needs a plain launch (one batch, no activation, out_f32 as the only output, no folds)");
@@ -156,7 +156,7 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   }
   if (a->batch2 < 0) return fail(FDM_ERR_ARG, "gemm: negative batch2");
   if (a->batch2 >= 1) {
-    const int tl = a->tile & ~FDM_TILE_GENERAL;
+    const int tl = a->tile & FDM_TILE_ID_MASK;
     if (a->ksplit > 1 || a->out_kp || a->out_vp || a->stat_out || a->ln_stat_in || a->sched_fuse || a->resid_row_mod || a->incr_counter)
       return fail(FDM_ERR_ARG, "gemm: batch2 cannot be combined with ksplit, packed K/V, LayerNorm folds, the fused scheduler or resid_row_mod");
     if (a->a_batch_stride2 % epc) return fail(FDM_ERR_ARG, "gemm: a_batch_stride2 needs 16-byte alignment");

@@ -420,8 +420,15 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_args p) {
+// LOADER WAVES (round 5, LW > 0).  Split K showed that the step's k loop is bounded per CU by throughput, not by the latency of
+// its tiles: per k-tile every wave issues its LDS-DMA pieces (each costs the ISSUING wave 60-185 cycles of back-pressure from the
+// memory pipe, MI355X_MICROARCH.md), reads its fragments and runs its MFMAs, in lockstep behind one barrier.  With LW > 0 the
+// WM x WN compute waves never issue a tile load: LW extra waves do nothing but wait for their pieces of tile kt (counted vmcnt),
+// meet the compute waves at the k-tile's barrier and request tile kt + NST - 1 -- the back-pressure stalls loader waves only, and
+// the loop runs at the L2 -> LDS rate of the CU instead of at the sum of its phases.  Same LDS image, same k order, same
+// epilogue: bit-identical to LW = 0 (FDM_TILE_LOCKSTEP selects it for A/B and tests).
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0, int LW = 0>
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const fdm_gemm_args p) {
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
   using E = typename Opnd<T>::E;
   constexpr int NP = Opnd<T>::NP;                // operand planes (2 for the split kinds: hi, lo)
@@ -433,9 +440,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   // 10 pieces on 8 waves) deals them out strided -- piece i * NW + wave -- and the first NA % NW waves carry one more: their
   // counted waits use their own piece count (a wave-uniform branch).
   constexpr int NA = BM / RPI, NWP = BN / RPI;
-  constexpr bool UNEVEN = NA % NW != 0;
-  static_assert(NWP % NW == 0 && BM % RPI == 0 && MI >= 1 && NI >= 1, "tile does not fit the wave grid");
-  constexpr int A_IPW = (NA + NW - 1) / NW, W_IPW = NWP / NW;
+  constexpr int IW = LW > 0 ? LW : NW;          // waves that issue the tile loads: the loader waves, or every wave
+  constexpr bool UNEVEN = NA % IW != 0;
+  static_assert(NWP % IW == 0 && BM % RPI == 0 && MI >= 1 && NI >= 1, "tile does not fit the wave grid");
+  constexpr int A_IPW = (NA + IW - 1) / IW, W_IPW = NWP / IW;
   constexpr int P = NP * (A_IPW + W_IPW), P_LO = NP * (A_IPW - 1 + W_IPW);
   constexpr int STAGE = NP * (BM + BN) * ROWB;   // [A planes][W planes]
   static_assert(NST * STAGE >= gemm_epi_ring_bytes<T, BM, BN>(), "epilogue staging does not fit in the ring");
@@ -456,8 +464,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   unsigned long long* stamps = (!p.incr_counter && p.incr_table) ? (unsigned long long*)p.incr_table + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
   if (stamps && tid == 0) { stamps[0] = wall_clock64(); stamps[5] = t_first; }
 #endif
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = LW > 0 && wave_id >= NW;
+  const int wave = LW > 0 ? (loader ? wave_id - NW : 0) : wave_id;      // index among the ISSUING waves (piece ownership below)
+  const int wm = wave_id / WN, wn = wave_id % WN;                        // compute-wave coordinates (unused by loader waves)
   const int g = lane >> 4, r16 = lane & 15;
   constexpr bool KSP = (SPEC & GEMM_KSPLIT) != 0, B2 = (SPEC & GEMM_B2) != 0;
   int z = KSP ? 0 : blockIdx.z;                  // batch index (a K-sliced launch is not batched)
@@ -504,7 +514,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   const char* w_src[W_IPW];
 #pragma unroll
   for (int i = 0; i < A_IPW; ++i) {
-    const int piece = UNEVEN ? min(i * NW + wave, NA - 1) : wave * A_IPW + i;
+    const int piece = UNEVEN ? min(i * IW + wave, NA - 1) : wave * A_IPW + i;
     const int row = RPI * piece + lrow;
     a_src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * p.lda) + ((slot ^ (row % KCH)) << 4);
   }
@@ -521,8 +531,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #pragma unroll
       for (int i = 0; i < A_IPW; ++i) {
         if constexpr (UNEVEN) {
-          if (i * NW + wave < NA)
-            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (i * NW + wave) * 1024), 16, 0, 0);
+          if (i * IW + wave < NA)
+            __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (i * IW + wave) * 1024), 16, 0, 0);
         } else {
           __builtin_amdgcn_global_load_lds((gptr_t)(a_src[i] + off + pl * a_lo), (lptr_t)(sb + pl * BM * ROWB + (wave * A_IPW + i) * 1024), 16, 0, 0);
         }
@@ -547,9 +557,26 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
   // wait of the kernel); the epilogue operands follow, younger than those tiles and older than every later one: the counted
   // waits of the first k iterations are stricter by their number until they have returned, and the loop's final vmcnt(0)
   // covers them in any case.
+  if (LW == 0 || loader) {
 #pragma unroll
-  for (int t = 0; t < NST - 1; ++t)
-    if (t < nk) issue(t);
+    for (int t = 0; t < NST - 1; ++t)
+      if (t < nk) issue(t);
+  }
+  if constexpr (LW > 0) {
+    if (loader) {
+      for (int kt = 0; kt < nk; ++kt) {
+        if (kt + NST - 2 < nk) {
+          if (!UNEVEN || wave < NA % IW) wait_vmcnt<(NST - 2) * P>();
+          else wait_vmcnt<(NST - 2) * P_LO>();
+        } else {
+          wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();           // tile kt landed (every loader's share); the compute waves are done with stage (kt-1) % NST
+        if (kt + NST - 1 < nk) issue(kt + NST - 1);
+      }
+      return;                                   // (a finished wave leaves the workgroup's barrier count: the epilogue's barriers are the compute waves')
+    }
+  }
   EpiPre<MI, NI> epre;
   constexpr bool FOLDC = !(SPEC & GEMM_LEAN) || (SPEC & GEMM_FOLD);
   gemm_epi_preload<T, BM, BN, WM, WN, SCHED>(pe, m0, n0, z, wm, wn, g, r16, FOLDC, epre);
@@ -576,11 +603,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 
   for (int kt = 0; kt < nk; ++kt) {
     // tile kt has landed once at most the (NST-2) younger tiles of this wave are still in flight
-    if (kt + NST - 2 < nk) {
-      if (!UNEVEN || wave < NA % NW) wait_vmcnt<(NST - 2) * P>();
-      else wait_vmcnt<(NST - 2) * P_LO>();
-    } else {
-      wait_vmcnt<0>();
+    if constexpr (LW == 0) {
+      if (kt + NST - 2 < nk) {
+        if (!UNEVEN || wave < NA % IW) wait_vmcnt<(NST - 2) * P>();
+        else wait_vmcnt<(NST - 2) * P_LO>();
+      } else {
+        wait_vmcnt<0>();
+      }
     }
     __builtin_amdgcn_s_barrier();           // everyone's part of tile kt landed; stage (kt-1)%NST is free
 #ifdef FDM_GEMM_STAMPS
@@ -601,7 +630,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) wf[s][ni][pl] = frag_w(base, pl, s, ni);
         }
-      if (kt + NST - 1 < nk) issue(kt + NST - 1);
+      if (LW == 0 && kt + NST - 1 < nk) issue(kt + NST - 1);
 #pragma unroll
       for (int s = 0; s < KCH / 4; ++s)
 #pragma unroll
@@ -609,7 +638,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #pragma unroll
           for (int ni = 0; ni < NI; ++ni) mma(mi, ni, wf[s][ni], af[s][mi]);
     } else {
-      if (kt + NST - 1 < nk) issue(kt + NST - 1);
+      if (LW == 0 && kt + NST - 1 < nk) issue(kt + NST - 1);
 #pragma unroll
       for (int s = 0; s < KCH / 4; ++s) {
         u32x4 af[MI][NP], wf[NI][NP];
@@ -637,6 +666,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_glds_kernel(const fdm_gemm_
 #ifdef FDM_GEMM_STAMPS
   if (stamps && tid == 0) stamps[2] = wall_clock64();
 #endif
+  if constexpr (LW > 0) wait_vmcnt<0>();      // the epilogue operands requested before the loop (a compute wave has no other load in flight)
   gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(pe, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
 #ifdef FDM_GEMM_STAMPS
   if (stamps && tid == 0) stamps[3] = wall_clock64();
@@ -920,17 +950,23 @@ static hipError_t gemm_pp_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false, int SPEC = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, bool HEAVY, bool SCHED = false, int SPEC = 0, int LW = 0>
 static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
   dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, (SPEC & GEMM_KSPLIT) ? a.ksplit : (a.batch > 0 ? a.batch : 1) * ((SPEC & GEMM_B2) ? a.batch2 : 1));
   constexpr int lds = NST * Opnd<T>::NP * (BM + BN) * KCH * 16 + gemm_ln_scratch_bytes<BM, BN>();
   static_assert(lds <= 160 * 1024, "ring does not fit the CU's LDS");
   static bool once = [] {
-    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
+    return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC>), grid, dim3(64 * WM * WN), lds, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC, LW>), grid, dim3(64 * (WM * WN + LW)), lds, s, a);
   return hipGetLastError();
+}
+// FDM_GEMM_LOCKSTEP=1 (env, read once): FDM_TILE_LOCKSTEP for every launch of the process -- A/B of the once-per-clip stages, whose
+// GEMMs carry no plan switch
+static bool gemm_lockstep_env() {
+  static bool v = [] { const char* e = getenv("FDM_GEMM_LOCKSTEP"); return e && atoi(e) != 0; }();
+  return v;
 }
 // Host mirror of the epilogue's `lean` predicate for EVERY tile of the launch: interior column tiles, vectorisable outputs /
 // residual, and (QKV projections) tile-aligned Q | K | V column ranges with whole packed chunks.
@@ -951,13 +987,13 @@ static bool gemm_all_tiles_lean(const fdm_gemm_args& a) {
   }
   return true;
 }
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8>
-static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH, int LW>
+static hipError_t gemm_glds_launch_lw(const fdm_gemm_args& a, hipStream_t s) {
   const bool no_lean = (a.tile & FDM_TILE_GENERAL) != 0;      // tests: the edge-handling kernel on a shape that does not need it
   if (a.ksplit > 1) {       // K-sliced launch (validated by fdm_op_gemm: plain fp32 output, no activation): the 64-column tiles only
     if constexpr (BN == 64 && (BM == 64 || BM == 32)) {
       if (!gemm_all_tiles_lean<T, BM, BN>(a)) return hipErrorInvalidValue;
-      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KSPLIT>(a, s);
+      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KSPLIT, LW>(a, s);
     } else {
       return hipErrorInvalidValue;
     }
@@ -965,25 +1001,35 @@ static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
   if (a.batch2 >= 1) {       // second batch level (validated by fdm_op_gemm): two kernels per tile, both with every activation compiled in
     if constexpr (BN == 64 && (BM == 64 || BM == 128)) {
       if (!no_lean && gemm_all_tiles_lean<T, BM, BN>(a) && a.out_batch_stride2 % 4 == 0)
-        return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_LEAN | GEMM_B2>(a, s);
-      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_B2>(a, s);
+        return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_LEAN | GEMM_B2, LW>(a, s);
+      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_B2, LW>(a, s);
     } else {
       return hipErrorInvalidValue;
     }
   }
   if (gemm_act_is_heavy(a.act)) {
     if (!no_lean && !a.out_kp && !a.out_vp && !a.stat_out && !a.ln_stat_in && gemm_all_tiles_lean<T, BM, BN>(a))
-      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_LEAN>(a, s);
-    return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true>(a, s);
+      return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, GEMM_LEAN, LW>(a, s);
+    return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, true, false, 0, LW>(a, s);
   }
   if (!no_lean && gemm_all_tiles_lean<T, BM, BN>(a)) {
     const bool kv = a.out_kp || a.out_vp, fold = a.stat_out || a.ln_stat_in;
-    if (kv && fold) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KV | GEMM_FOLD>(a, s);
-    if (kv) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KV>(a, s);
-    if (fold) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_FOLD>(a, s);
-    return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN>(a, s);
+    if (kv && fold) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KV | GEMM_FOLD, LW>(a, s);
+    if (kv) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_KV, LW>(a, s);
+    if (fold) return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN | GEMM_FOLD, LW>(a, s);
+    return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, GEMM_LEAN, LW>(a, s);
   }
-  return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false>(a, s);
+  return gemm_glds_launch_h<T, BM, BN, WM, WN, NST, KCH, false, false, 0, LW>(a, s);
+}
+
+// Tile launcher: the loader-wave form (LW_ waves that only issue the tile loads) for the 16-bit operand kinds unless the caller asks
+// for the lockstep loop (FDM_TILE_LOCKSTEP: A/B and tests -- the two are bit-identical); fp32 is MFMA-bound and keeps the lockstep loop.
+template <typename T, int BM, int BN, int WM, int WN, int NST, int LW_ = 0, int KCH = 8>
+static hipError_t gemm_glds_launch_t(const fdm_gemm_args& a, hipStream_t s) {
+  if constexpr (LW_ > 0 && !std::is_same<T, float>::value) {
+    if (!(a.tile & FDM_TILE_LOCKSTEP) && !gemm_lockstep_env()) return gemm_glds_launch_lw<T, BM, BN, WM, WN, NST, KCH, LW_>(a, s);
+  }
+  return gemm_glds_launch_lw<T, BM, BN, WM, WN, NST, KCH, 0>(a, s);
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NST>
@@ -1022,6 +1068,14 @@ static bool gemm_one_round_80(const fdm_gemm_args& a) {
   return t80 > 224 && t80 <= 256 && (a.M % 80 == 0 || a.M % 80 > 40);   // (a mostly empty last row tile wastes the round)
 }
 
+// 64x128 tiles that fill the chip in exactly one round for a wide projection (FFN1 at the step's 800 rows: 13 x 16 = 208 workgroups): with
+// loader waves (round 5) the k loop runs at the CU's L2 -> LDS rate, so the tile with fewer bytes per CU wins -- 8.45 us against 9.71 for two
+// co-resident 64x64 tiles per CU in bf16, 14.9 against 18.7 in f16x3 (profiles/r5_ldw/isolated.txt)
+static bool gemm_one_round_64x128(const fdm_gemm_args& a) {
+  const long long t = (long long)((a.M + 63) / 64) * ((a.N + 127) / 128) * (a.batch > 0 ? a.batch : 1);
+  return gemm_one_round(t) && a.N >= 2048 && a.N % 128 == 0;
+}
+
 // elem_bytes: 4 (fp32) or 2; split: the two-plane kinds (a ring stage is twice as large there, so their tile set is the part
 // of the one-plane set whose ring fits 160 KB of LDS)
 static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool split) {
@@ -1048,6 +1102,7 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
     if (elem_bytes == 2 && a.M > 1024 && t128 >= thr128 && gemm_one_round(t256)) return FDM_TILE_256x128_PP;
     if (t128 >= thr128) return FDM_TILE_128x128;
     if (gemm_one_round_80(a)) return FDM_TILE_80x128;
+    if (elem_bytes == 2 && gemm_one_round_64x128(a)) return FDM_TILE_64x128;
     // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two
     //  64 KB rings per CU -- stay on it: MEAD's d = 512 sites at 1200-1600 rows lost 3-5 % on larger tiles)
     if (elem_bytes == 2 && a.M > 1024 && (t64 > 512 || a.K >= 1024)) {
@@ -1063,6 +1118,7 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
   }
   if (t128 >= 512) return FDM_TILE_128x128;
   if (gemm_one_round_80(a)) return FDM_TILE_80x128;
+  if (gemm_one_round_64x128(a)) return FDM_TILE_64x128;
   if (a.M > 1024) {            // the tuner's picks at 1100..4000 rows as rules (see above)
     if (gemm_one_round(t128)) return FDM_TILE_128x128;
     if (t128x64 > 128 && t128x64 <= 256) return FDM_TILE_128x64;     // (split kinds: 3-stage, 144 KB ring -- one per CU, so one round only)
@@ -1083,15 +1139,27 @@ static bool gemm_sched_fuse_heuristic_pp(const fdm_gemm_args& a, int elem_bytes)
   return gemm_heuristic_tile(b, elem_bytes, false) == FDM_TILE_256x128_PP;
 }
 
+// the scheduler-fused latent decoder on the 64x64 tile (lean kernels only), loader-wave form for the 16-bit kinds
+template <typename T>
+static hipError_t gemm_sched_fuse_launch(const fdm_gemm_args& a, hipStream_t s) {
+  if constexpr (!std::is_same<T, float>::value) {
+    if (!(a.tile & FDM_TILE_LOCKSTEP) && !gemm_lockstep_env())
+      return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD, 4>(a, s)
+                          : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN, 4>(a, s);
+  }
+  return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
+                      : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
+}
+
 // K-sliced launches (fdm_gemm_args.ksplit): the 64-column tiles, ring depth by tile id.  With S slices per output tile the grid
 // is S times as large and a slice's chain 1 / S as long, so shallower rings (more co-resident slices per CU) are the candidates.
 static int gemm_ksplit_heuristic_tile(const fdm_gemm_args& a) { return a.M <= 128 ? FDM_TILE_32x64_S3 : FDM_TILE_64x64; }   // (profiles/r5_splitk/)
 template <typename T>
 static hipError_t gemm_dispatch_ksplit(const fdm_gemm_args& a, int tile_id, hipStream_t s) {
   switch (tile_id > 0 ? tile_id : gemm_ksplit_heuristic_tile(a)) {
-    case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);
-    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);
-    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);
+    case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2, 4>(a, s);
+    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3, 2>(a, s);
+    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4, 4>(a, s);
   }
 }
 
@@ -1099,14 +1167,13 @@ template <typename T>
 static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   if (a.sched_fuse) {     // (validated: interior tiles only -> the lean epilogue)
     // thousands of rows: the scheduler-fused latent decoder on the ping-pong tile when the plan's tuner picked it
-    const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+    const int tile_id = a.tile & FDM_TILE_ID_MASK;
     const bool pp = tile_id == FDM_TILE_256x128_PP || (tile_id == 0 && gemm_tile_override() == 0 && gemm_sched_fuse_heuristic_pp(a, (int)sizeof(typename Opnd<T>::E)));
     if (pp && !a.ln_stat_in && a.N % 128 == 0)
       return gemm_pp_launch_h<T, 256, 128, 4, 2, 3, false, true, GEMM_LEAN>(a, s);
-    return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
-                        : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
+    return gemm_sched_fuse_launch<T>(a, s);
   }
-  const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+  const int tile_id = a.tile & FDM_TILE_ID_MASK;
   if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
   const int want = tile_id > 0 ? tile_id : gemm_tile_override();
   switch (want > 0 ? want : gemm_heuristic_tile(a, (int)sizeof(typename Opnd<T>::E), false)) {
@@ -1114,17 +1181,17 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_128x64: {                                                        // 8 waves, 32x32 per wave
       // 4-stage ring (96 KB, one per CU) while the grid is one round; beyond that the 3-stage ring (72 KB): two workgroups per CU
       const long long wgs = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * (a.batch > 0 ? a.batch : 1) * (a.batch2 > 0 ? a.batch2 : 1);
-      return wgs <= 256 ? gemm_glds_launch_t<T, 128, 64, 4, 2, 4>(a, s) : gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);
+      return wgs <= 256 ? gemm_glds_launch_t<T, 128, 64, 4, 2, 4, 4>(a, s) : gemm_glds_launch_t<T, 128, 64, 4, 2, 3, 4>(a, s);
     }
     case FDM_TILE_96x128:                                                          // (retired id: nearest member)
-    case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3>(a, s);  // 8 waves, 64x32 per wave
-    case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);    // 32 KB -> 4 workgroups per CU
-    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);    // 4 waves, 16x32 per wave, 36 KB
+    case FDM_TILE_128x128: return gemm_glds_launch_t<T, 128, 128, 2, 4, 3, 4>(a, s);  // 8 waves, 64x32 per wave
+    case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2, 4>(a, s);    // 32 KB -> 4 workgroups per CU
+    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3, 2>(a, s);    // 4 waves, 16x32 per wave, 36 KB
     case FDM_TILE_256x128:                                                           // (retired id: the lockstep loop on this tile)
     case FDM_TILE_256x128_PP: return gemm_pp_launch_t<T, 256, 128, 4, 2, 3>(a, s);   // ping-pong loop, 64x64 per wave, 146 KB
-    case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 4>(a, s);      // 8 waves, 80x16 per wave: 800 rows x 3072 = 240 workgroups
-    case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4>(a, s);      // 8 waves, 32x32 per wave
-    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                    // FDM_TILE_64x64: 8 waves, 32x16 per wave
+    case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 4, 4>(a, s);      // 8 waves, 80x16 per wave: 800 rows x 3072 = 240 workgroups
+    case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 4, 4>(a, s);      // 8 waves, 32x32 per wave
+    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4, 4>(a, s);                    // FDM_TILE_64x64: 8 waves, 32x16 per wave
   }
 }
 
@@ -1133,23 +1200,22 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
 template <typename T>
 static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
   if (a.sched_fuse)
-    return a.ln_stat_in ? gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN | GEMM_FOLD>(a, s)
-                        : gemm_glds_launch_h<T, 64, 64, 2, 4, 4, 8, false, true, GEMM_LEAN>(a, s);
-  const int tile_id = a.tile & ~FDM_TILE_GENERAL;
+    return gemm_sched_fuse_launch<T>(a, s);
+  const int tile_id = a.tile & FDM_TILE_ID_MASK;
   if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
   const int want = tile_id > 0 ? tile_id : gemm_tile_override();
   switch (want > 0 ? want : gemm_heuristic_tile(a, 2, true)) {
-    case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2>(a, s);  // 64 KB -> 2 workgroups per CU
-    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3>(a, s);  // 72 KB -> 2 workgroups per CU
+    case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2, 4>(a, s);  // 64 KB -> 2 workgroups per CU
+    case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3, 2>(a, s);  // 72 KB -> 2 workgroups per CU
     case FDM_TILE_128x64:
-    case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3>(a, s);   // 144 KB
+    case FDM_TILE_128x64_S3: return gemm_glds_launch_t<T, 128, 64, 4, 2, 3, 4>(a, s);   // 144 KB
     case FDM_TILE_128x128:
     case FDM_TILE_96x128:
     case FDM_TILE_256x128:
-    case FDM_TILE_256x128_PP: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2>(a, s);    // 128 KB, one tile in flight
-    case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 3>(a, s);      // 156 KB
-    case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 3>(a, s);      // 144 KB
-    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4>(a, s);                    // FDM_TILE_64x64: 128 KB ring
+    case FDM_TILE_256x128_PP: return gemm_glds_launch_t<T, 128, 128, 2, 4, 2, 4>(a, s);    // 128 KB, one tile in flight
+    case FDM_TILE_80x128: return gemm_glds_launch_t<T, 80, 128, 1, 8, 3, 4>(a, s);      // 156 KB
+    case FDM_TILE_64x128: return gemm_glds_launch_t<T, 64, 128, 2, 4, 3, 4>(a, s);      // 144 KB
+    default: return gemm_glds_launch_t<T, 64, 64, 2, 4, 4, 4>(a, s);                    // FDM_TILE_64x64: 128 KB ring
   }
 }
 

@@ -241,6 +241,7 @@ struct fdm_plan {
   // partial planes of x1, summed by that launch (fdm_gemm_args.ksplit / fdm_ln_args.x_planes).  A property of the plan, NOT of the
   // shape: results depend on S, and a clip must compute the same bits in every batch composition.
   int ksplit_out = 1, ksplit_ffn2 = 1;
+  int lockstep = 0;                          // fdm_plan_set "lockstep": the lockstep k loop in every GEMM of the step (A/B against the loader-wave form; same bits)
   int tune_lazy = 0;                         // 1: fdm_sample_graph may tune in-call once a shape has run 2000 steps (opt-in)
   long long last_graph_launches = 0, launches_per_step = 0;
 };
@@ -326,7 +327,7 @@ int to_operand(fdm_plan* P, const float* src, long long n, Mat* out, void* strea
 int plan_gemm(fdm_plan* P, const char* label, fdm_gemm_args a, void* stream) {
   if (P->tune_rec) (*P->tune_rec)[label].push_back(a);
   auto it = P->tiles.find(label);
-  a.tile = it == P->tiles.end() ? 0 : it->second;
+  a.tile = (it == P->tiles.end() ? 0 : it->second) | (P->lockstep ? FDM_TILE_LOCKSTEP : 0);
   return fdm_op_gemm(&a, stream);
 }
 
@@ -677,7 +678,7 @@ std::string tiles_sig(const fdm_plan* P) {
   std::string s;
   for (auto& kv : P->tiles)
     if (kv.second) s += kv.first + "=" + std::to_string(kv.second) + ",";
-  s += "ks" + std::to_string(P->ksplit_out) + std::to_string(P->ksplit_ffn2);
+  s += "ks" + std::to_string(P->ksplit_out) + std::to_string(P->ksplit_ffn2) + (P->lockstep ? "L" : "");
   return s;
 }
 
@@ -932,7 +933,7 @@ int tune_tiles_impl(fdm_plan* P, void* stream) {
       fdm_prog* prog = nullptr;
       FCK(fdm_prog_create(&prog));
       int rc = fdm_prog_begin(prog);
-      for (size_t i = 0; rc == FDM_OK && i < inst.size(); ++i) { fdm_gemm_args a = inst[i]; a.tile = tile; a.incr_counter = nullptr; a.incr_table = nullptr; rc = fdm_op_gemm(&a, stream); }
+      for (size_t i = 0; rc == FDM_OK && i < inst.size(); ++i) { fdm_gemm_args a = inst[i]; a.tile = tile | (P->lockstep ? FDM_TILE_LOCKSTEP : 0); a.incr_counter = nullptr; a.incr_table = nullptr; rc = fdm_op_gemm(&a, stream); }
       (void)fdm_prog_end(prog);
       float ms = 0.f;
       if (rc == FDM_OK) rc = time_prog(prog, 2, 5, s, &ms);
@@ -1346,6 +1347,7 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
     P->tile_cache.clear(); P->tiles.erase(k == "ksplit.out" ? "out" : "ffn2");
     return drop_programs(P, nullptr);
   }
+  if (k == "lockstep") { P->lockstep = value != 0; P->tile_cache.clear(); P->tiles.clear(); return drop_programs(P, nullptr); }
   if (k == "untune") {      // forget the tuned tiles of every shape (tests)
     P->tile_cache.clear(); P->steps_seen.clear(); P->tiles.clear(); P->tune_failed_shapes.clear();
     return drop_programs(P, nullptr);

@@ -192,6 +192,10 @@ typedef struct fdm_gemm_args {
  * bit (tests/test_ops_gpu.py); not a tuning knob.  Honoured by every tile including the ping-pong one; the scheduler-fused latent
  * decoder (sched_fuse) has lean kernels only and ignores it. */
 #define FDM_TILE_GENERAL 0x100
+/* or-ed into `tile`: the lockstep k loop (every wave issues its own tile loads) instead of the loader-wave form the 16-bit kinds run
+ * by default (round 5) -- the two are bit-identical (tests/test_ops_gpu.py); A/B measurements and tests, not a tuning knob */
+#define FDM_TILE_LOCKSTEP 0x200
+#define FDM_TILE_ID_MASK 0xff
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream);
 /* The FDM_TILE_* value a launch of *a with tile = 0 resolves to (the library heuristic on M, N, K, batch and the operand kind;
  * no device work, a->tile is ignored).  The plan-time tuner uses it to leave the heuristic's own tile out of its candidates. */

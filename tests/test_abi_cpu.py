@@ -181,9 +181,10 @@ def test_tile_heuristic_is_a_pure_function_of_the_shape():
     assert l.fdm_gemm_heuristic_tile(None) == -1
     B, F, S = _lib.BF16, _lib.F32, _lib.F16X3
     assert tile(B, 800, 3072, 1024) == _lib.TILE_80x128 and tile(S, 800, 3072, 1024) == _lib.TILE_80x128 and tile(F, 800, 3072, 1024) == _lib.TILE_80x128
-    assert tile(B, 800, 1024, 1024) == _lib.TILE_64x64 and tile(B, 800, 1024, 2048) == _lib.TILE_64x64 and tile(B, 800, 2048, 1024) == _lib.TILE_64x64
+    assert tile(B, 800, 1024, 1024) == _lib.TILE_64x64 and tile(B, 800, 1024, 2048) == _lib.TILE_64x64
+    assert tile(B, 800, 2048, 1024) == _lib.TILE_64x128 and tile(S, 800, 2048, 1024) == _lib.TILE_64x128 and tile(F, 800, 2048, 1024) == _lib.TILE_64x64      # FFN1: 13 x 16 = 208 tiles, one round
     assert tile(B, 100, 1024, 1024) == _lib.TILE_64x64 and tile(S, 100, 1024, 1024) == _lib.TILE_32x64_S3
-    assert tile(S, 600, 3072, 1024) == _lib.TILE_64x64_S2 and tile(S, 800, 1024, 1024) == _lib.TILE_64x64
+    assert tile(S, 600, 3072, 1024) == _lib.TILE_64x128 and tile(S, 400, 3072, 1024) == _lib.TILE_64x64_S2 and tile(S, 800, 1024, 1024) == _lib.TILE_64x64      # 10 x 24 = 240 one-round tiles | 7 x 48 = 336 tiles on the 2-stage ring
     assert tile(B, 1992, 2048, 1024) == _lib.TILE_128x128 and tile(S, 1992, 2048, 1024) == _lib.TILE_128x128      # 16 x 16 = 256 tiles
     assert tile(B, 2400, 3072, 1024) == _lib.TILE_256x128_PP                                                         # 10 x 24 = 240 tiles
     assert tile(B, 1200, 1024, 1024) == _lib.TILE_128x64 and tile(B, 3000, 1024, 1024) == _lib.TILE_128x64 and tile(B, 3200, 1024, 1024) == _lib.TILE_128x128

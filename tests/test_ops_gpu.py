@@ -789,12 +789,12 @@ def test_specialised_and_general_gemm_kernels_agree_bitwise():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hashes = []
-    for general in ("0", "1"):
+    for general in ("0", "1", "2", "3"):      # default | FDM_TILE_GENERAL | FDM_TILE_LOCKSTEP (no loader waves) | both
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_variant_hash.py"), general], cwd=root,
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout + r.stderr
         hashes.append([ln for ln in r.stdout.splitlines() if ln.startswith("variant hash")][0])
-    assert hashes[0] == hashes[1]
+    assert hashes[0] == hashes[1] == hashes[2] == hashes[3]
 
 
 def test_time_groupnorm_single_launch_and_chunked_forms():

@@ -1,6 +1,7 @@
 """One hash over the outputs of a fixed set of GEMM launches that exercise every specialised kernel variant (plain, heavy
 activation, packed K / V with aligned and unaligned clip lengths, LayerNorm-fold producer / consumer, fused scheduler, batched).
-Run with argument 1 (FDM_TILE_GENERAL or-ed into every tile: general kernels everywhere) and 0 (the default dispatch): the hashes must be equal
+Run with argument 1 (FDM_TILE_GENERAL or-ed into every tile: general kernels everywhere), 2 (FDM_TILE_LOCKSTEP: the lockstep k loop instead of
+the loader-wave form), 3 (both) and 0 (the default dispatch): the hashes must be equal
 (tests/test_ops_gpu.py::test_specialised_and_general_gemm_kernels_agree_bitwise)."""
 import hashlib
 import math
@@ -34,9 +35,9 @@ def out_t(M, N, dt):
 
 
 g = torch.Generator().manual_seed(5)
-GEN = 0x100 if (len(sys.argv) > 1 and sys.argv[1] == '1') else 0      # include/fdm_hip.h FDM_TILE_GENERAL
+GEN = {'1': 0x100, '2': 0x200, '3': 0x300}.get(sys.argv[1] if len(sys.argv) > 1 else '0', 0)      # include/fdm_hip.h FDM_TILE_GENERAL (0x100), FDM_TILE_LOCKSTEP (0x200)
 for dt in (BF16, F32, F16X3):
-    for tile in (0 | GEN, 2 | GEN, 3 | GEN, 8 | GEN, 10 | GEN):      # (10 = the ping-pong tile: its launcher honours FDM_TILE_GENERAL too)
+    for tile in (0 | GEN, 2 | GEN, 3 | GEN, 8 | GEN, 10 | GEN, 9 | GEN, 11 | GEN, 12 | GEN):      # (10 = the ping-pong tile: its launcher honours FDM_TILE_GENERAL too)
         # plain / heavy, interior and edge shapes
         for (M, N, K, act) in ((800, 1024, 1024, ACT_NONE), (130, 2048, 512, ACT_RELU), (64, 1024, 1024, ACT_MISH), (77, 192, 256, ACT_RELU)):
             A, W = opnd(torch.randn(M, K, generator=g), dt), opnd(torch.randn(N, K, generator=g) / math.sqrt(K), dt)
@@ -45,7 +46,7 @@ for dt in (BF16, F32, F16X3):
             ops.gemm(A, W, M, N, K, bias=bias, act=act, resid=res, out_f32=o32, out_t=ot, tile=tile)
             add(o32, *([ot] if ot is not None else []))
         # QKV projection into the packed K / V layouts: clip lengths that are / are not whole packed chunks
-        if dt != F16X3 or (tile & 0xff) in (0, 3, 8):
+        if (dt != F16X3 or (tile & 0xff) in (0, 3, 8)) and (tile & 0xff) not in (9, 11, 12):
             for (B, L) in ((4, 200), (2, 498), (3, 33)):
                 d, H = 512, 4
                 hd, M = d // H, B * L
