@@ -17,8 +17,8 @@ from fdm_amd import ops  # noqa: E402
 from fdm_amd._lib import DTYPE_NAMES, F32  # noqa: E402
 
 DEV = "cuda:0"
-TILES = {0: "auto", 1: "64x64", 2: "128x64", 3: "128x128", 5: "256x128", 6: "64x64_s3", 7: "128x64_s3", 8: "64x64_s2",
-         9: "32x64_s3", 10: "256x128_pp", 11: "80x128", 12: "64x128"}
+TILES = {0: "auto", 1: "64x64", 2: "128x64", 3: "128x128", 8: "64x64_s2", 9: "32x64_s3", 10: "256x128_pp", 11: "80x128", 12: "64x128",
+         0x201: "64x64 lockstep", 0x202: "128x64 lockstep"}      # (0x200 = FDM_TILE_LOCKSTEP: the loop without loader waves)
 
 
 def timeit(fn, n_rec=8, reps=10):

@@ -16,7 +16,7 @@ for dt in (BF16, F32):
         res = torch.randn(M, N, generator=g).to(DEV)
         ref = torch.zeros(M, N, device=DEV)
         ops.gemm(A, W, M, N, K, bias=bias, act=ACT_RELU, resid=res, out_f32=ref, tile=1)
-        for tile in range(2, 13):
+        for tile in list(range(2, 13)) + [0x200 | t for t in (1, 2, 3, 8, 9, 11, 12)]:      # (0x200 = FDM_TILE_LOCKSTEP: no loader waves)
             out = torch.zeros(M, N, device=DEV)
             for rep in range(3):        # races would show as run-to-run differences
                 ops.gemm(A, W, M, N, K, bias=bias, act=ACT_RELU, resid=res, out_f32=out, tile=tile)
