@@ -8,15 +8,17 @@ from fdm_amd import synth as W
 DEV = 'cuda:0'
 # (round 3: + 32 clips per GPU = 6400 rows, where the tuner picks the ping-pong tile; + 8 style conditions per clip; + BIWI in f16x3:
 #  the streamed split attention kernel at head_dim 256)
-for preset, B, L, T, cfg, dt, reps in (("vocaset", 32, 200, 120, False, BF16, 4), ("vocaset", 1, 100, 99, False, BF16, 4), ("biwi", 4, 200, 250, False, F16X3, 3),
+for preset, B, L, T, cfg, dt, reps in (("vocaset", 32, 200, 120, False, BF16, 4), ("vocaset", 1, 100, 99, False, BF16, 4), ("vocaset", 1, 100, 400, "single", BF16, 4), ("mead", 1, 249, 400, "single", F16X3, 3), ("biwi", 4, 200, 250, False, F16X3, 3),
                                        ("vocaset", 4, 200, 1000, False, BF16, 6), ("vocaset", 4, 498, 400, False, BF16, 4),
                                        ("mead", 4, 300, 400, True, BF16, 4), ("vocaset", 4, 200, 300, False, F32, 3),
                                        ("biwi", 4, 200, 250, False, BF16, 4), ("vocaset", 4, 200, 1000, False, F16X3, 4),
                                        ("mead", 4, 300, 400, True, F16X3, 3), ("vocaset", 4, 498, 300, False, F16X3, 3)):
     inp = W.synth_inputs(preset, B, L, seed=2)
     plan = DenoiserPlan(preset, W.make_fdm_weights(preset), dt, DEV)
+    if cfg == "single":        # (round 5: the single-clip setting -- K slices of the out-proj / FFN2 GEMMs; every 16-bit GEMM runs the loader-wave loop)
+        plan.set("ksplit.out", 2); plan.set("ksplit.ffn2", 4); cfg = False
     hub = inp["hub"][:, :, :768].contiguous() if preset == "biwi" else inp["hub"]
-    S = 8 if (B == 1 and L == 100) else 1
+    S = 8 if (B == 1 and L == 100 and T == 99) else 1
     style = torch.eye(8)[:S].repeat(B, 1) if S > 1 else inp["style"]
     plan.prepare(hub, style, inp.get("emo"), L=L, cfg=cfg, n_conds=S)
     plan.tune()
