@@ -72,6 +72,57 @@ def test_argument_validation_of_the_round1_additions():
     assert l.fdm_op_linear_interp(16, 16, 1, 0, 5, 4, None) == -1
 
 
+def test_argument_validation_of_the_round5_additions():
+    """K slices (fdm_gemm_args.ksplit / fdm_ln_args.x_planes), the second batch level (batch2), the lockstep flag and the retired tile
+    ids: bad arguments are reported before anything is launched; retired ids and the lockstep flag are accepted (recorded here)."""
+    from fdm_amd import _lib
+    l = _lib.lib()
+
+    def args():
+        a = _lib.GemmArgs()
+        a.A, a.W, a.M, a.N, a.K, a.dtype, a.lda, a.ldw, a.out_f32, a.ldo_f32, a.ldr, a.ldo_t = 16, 16, 64, 128, 1024, _lib.BF16, 1024, 1024, 16, 128, 128, 128
+        a.batch = 1
+        return a
+    a = args(); a.ksplit = 5
+    assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"ksplit" in l.fdm_last_error()
+    a = args(); a.ksplit, a.ksplit_stride = 3, 64 * 128                     # 16 k-tiles are not divisible by 3
+    assert l.fdm_op_gemm(C.byref(a), None) == -2 and b"does not divide" in l.fdm_last_error()
+    a = args(); a.ksplit, a.ksplit_stride, a.act = 2, 64 * 128, _lib.ACT_RELU
+    assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"plain launch" in l.fdm_last_error()
+    a = args(); a.ksplit, a.ksplit_stride = 2, 100                           # shorter than one output plane
+    assert l.fdm_op_gemm(C.byref(a), None) == -2
+    a = args(); a.ksplit, a.ksplit_stride, a.tile = 2, 64 * 128, _lib.TILE_128x128
+    assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"64-column tiles" in l.fdm_last_error()
+    a = args(); a.batch2, a.ksplit, a.ksplit_stride = 2, 2, 64 * 128
+    assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"batch2" in l.fdm_last_error()
+    a = args(); a.batch2, a.tile = 2, _lib.TILE_80x128
+    assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"batch2 runs on" in l.fdm_last_error()
+    ln = _lib.LnArgs()
+    ln.x, ln.gamma, ln.beta, ln.M, ln.d, ln.y_f32, ln.dtype = 16, 16, 16, 4, 256, 16, _lib.F32
+    ln.x_planes, ln.x_plane_stride = 5, 4096
+    assert l.fdm_op_layernorm(C.byref(ln), None) == -1 and b"x_planes" in l.fdm_last_error()
+    ln.x_planes, ln.x_plane_stride = 2, 512                                  # < M * d
+    assert l.fdm_op_layernorm(C.byref(ln), None) == -1
+    # accepted forms, recorded (nothing is launched on this machine)
+    h = C.c_void_p()
+    assert l.fdm_prog_create(C.byref(h)) == 0 and l.fdm_prog_begin(h) == 0
+    for tile in (_lib.TILE_64x64 | 0x200, _lib.TILE_64x64_S3, _lib.TILE_128x64_S3, _lib.TILE_256x128, _lib.TILE_96x128 | 0x100):
+        a = args(); a.tile = tile
+        assert l.fdm_op_gemm(C.byref(a), None) == 0, tile
+    a = args(); a.ksplit, a.ksplit_stride, a.tile = 4, 64 * 128, _lib.TILE_32x64_S3
+    assert l.fdm_op_gemm(C.byref(a), None) == 0
+    a = args(); a.batch, a.batch2, a.tile = 16, 3, _lib.TILE_128x64
+    assert l.fdm_op_gemm(C.byref(a), None) == 0
+    ln.x_planes, ln.x_plane_stride = 4, 1024
+    assert l.fdm_op_layernorm(C.byref(ln), None) == 0
+    assert l.fdm_prog_end(h) == 0 and l.fdm_prog_num_ops(h) == 8 and l.fdm_prog_destroy(h) == 0
+    assert l.fdm_version() == _lib.LIB_VERSION == 105
+    import ctypes
+    for sym in ("fdm_prog_set_lane", "fdm_prog_run_lanes"):                 # removed this round
+        with pytest.raises(AttributeError):
+            getattr(ctypes.CDLL(_lib.LIB_PATH), sym)
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from fdm_amd import _lib, ops
