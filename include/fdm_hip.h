@@ -431,7 +431,8 @@ int fdm_sample_graph(fdm_plan* p, const fdm_sample_args* a, void* stream);
  * set); FDM_TUNE_VERBOSE=1 prints its choices; FDM_TILE_OVERRIDE="qkv=3,ffn1=2" pins call sites (applied at fdm_audio_prepare*,
  * with or without the tuner); FDM_TILE_CACHE=<file> (opt-in) keeps tuned sets across processes: a tuning run appends
  * "<version|mode|geometry|shape>\t<site>=<tile>,..." (temporary file + rename), and fdm_audio_prepare* takes a stored set for its
- * shape without any timing launch; FDM_GEMM_TILE=<FDM_TILE_*> forces one tile for every fdm_op_gemm with tile = 0 (A/B sweeps). */
+ * shape without any timing launch; FDM_GEMM_TILE=<FDM_TILE_*> forces one tile for every fdm_op_gemm with tile = 0 (A/B sweeps);
+ * FDM_GEMM_LOCKSTEP=1 = FDM_TILE_LOCKSTEP for every fdm_op_gemm of the process (A/B of the once-per-clip stages; the step has fdm_plan_set "lockstep"). */
 int fdm_plan_tune(fdm_plan* p, void* stream);
 /* Introspection / experiments: integer properties by name -- "launches_per_step", "graph_launches" (host graph launches of
  * the last fdm_sample_graph), "rows", "tuned", "needs_tune", "tune_failed", "fuse_ln3", "tile.<call site>" (qkv, out, ffn1, ffn2,
