@@ -232,7 +232,7 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("FDM_DIST_FORCE") == "1":      # (FDM_DIST_FORCE: a ONE-rank process group -- the RCCL branch on a 1-GPU box, tests)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("FDM_DIST_BACKEND", "nccl")     # "nccl" is RCCL on ROCm; gloo only for 1-GPU dry runs

@@ -22,7 +22,7 @@ def gather_clips(local, dist=None, sizes=None):
 
     dist: the torch.distributed module (initialised) or None for a single process.  Ragged shards are
     padded to the largest shard for the collective and trimmed afterwards."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return local
     world = dist.get_world_size()
     if dist.get_backend() != "nccl" and local.is_cuda:      # gloo dry runs: stage through host memory

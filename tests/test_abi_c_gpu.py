@@ -125,6 +125,29 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     assert a.shape == b.shape == (4, 498, 15069) and np.isfinite(a).all() and np.array_equal(a, b)
 
 
+def test_rccl_branch_of_bench_runs_with_one_rank(tmp_path):
+    """The RCCL transport cannot be exercised across GPUs here (no multi-GPU node), but the branch that uses it can: `bench.py` with a
+    ONE-rank `nccl` process group (FDM_DIST_FORCE=1) initialises RCCL on the device, gathers the clips with a device all-gather,
+    reduces the timing with a device all-reduce and barriers through RCCL -- same line, same bits as the plain single-process run."""
+    import json
+    import socket
+    import sys
+    import numpy as np
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    bench = os.path.join(ROOT, "bench.py")
+    common = [sys.executable, bench, "--config", "cfg1", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--headline-only", "--dtype", "f16x3", "--gpus", "1"]
+    one, two = str(tmp_path / "plain.npy"), str(tmp_path / "rccl.npy")
+    r = subprocess.run(common + ["--dump", one], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FDM_DIST_FORCE="1")
+    env.pop("FDM_DIST_BACKEND", None)
+    r = subprocess.run(common + ["--dump", two], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["dist_backend"] == "nccl" and rec["rccl_ranks"] == 1 and rec["n_gpus"] == 1
+    assert np.array_equal(np.load(one), np.load(two))
+
+
 @pytest.mark.parametrize("config", ["shipped_biwi", "shipped_vocaset"])
 def test_bench_shipped_configs_print_a_complete_line(config):
     """bench.py --config shipped_* (what the reference's samplers issue per test clip, end to end inside the timed call): one JSON
