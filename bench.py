@@ -370,23 +370,6 @@ def main():
                 mark()
             return gather_clips(out, dist, sizes=[B * S] * world) if collect else out     # equal shards: no size exchange
 
-        if dist is not None and os.environ.get("FDM_BENCH_TAKE_TURNS") == "1":
-            # ONE-GPU dry runs only (tests/test_abi_c_gpu.py: N ranks as N processes on this box's single GPU): the ranks' device
-            # work takes turns.  Two HuBERT-large encoders co-running on ONE device are not bit-reproducible (DESIGN.md section 7,
-            # known issue: present in the round-4 library too, every stage clean in isolation); on a multi-GPU node every rank
-            # owns its GPU and nothing takes turns.
-            rank_local = one_call
-
-            def one_call(collect=True, marks=None):       # noqa: F811
-                out = None
-                for r in range(world):
-                    if r == rank:
-                        out = rank_local(False, marks)
-                        torch.cuda.synchronize()
-                    if collect:
-                        dist.barrier()
-                return gather_clips(out, dist, sizes=[B * S] * world) if collect else out
-
         el, ev_ms, out = timed(one_call, steps, warmup)
         assert torch.isfinite(out).all()
         n_launch = steps * n_live

@@ -253,9 +253,12 @@ __global__ __launch_bounds__(256) void conv0_kernel(const float* wav, const floa
     const int t = t0 + tt;
     if (t >= T0) break;
     float xa = 0.f, xb = 0.f;
+    // (the frame's ten samples through ONE vector load + readlane, not through the scalar data cache: see conv0_ln_gelu_kernel)
+    const int lane = threadIdx.x & 63;
+    const float xs = lane < 10 ? wv[5 * t + lane] : 0.f;
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
-      const float x = wv[5 * t + k];
+      const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), k));
       xa = fmaf(wa[k], x, xa);
       xb = fmaf(wb[k], x, xb);
     }
@@ -292,9 +295,14 @@ __global__ __launch_bounds__(256) void conv0_ln_gelu_kernel(const float* wav, co
   for (int f = 0; f < FPW; ++f) {
     const int t = f0 + f;                     // (wave-uniform)
     if (t >= T0) break;
+    // The frame's ten samples: ONE vector load by lanes 0..9, handed to every lane through readlane.  (Round 4 read them with
+    // wave-uniform addresses, i.e. through the scalar data cache: bit-stable in a process that owns the device, but with a second
+    // process on the same GPU a handful of the 128 k frames came back wrong on every call -- the only kernel of the library that
+    // pulled bulk data through the scalar cache, and the only stage of the encoder that was not reproducible there: round 5.)
+    const float xs = lane < 10 ? wv[5 * t + lane] : 0.f;
     float x[10];
 #pragma unroll
-    for (int k = 0; k < 10; ++k) x[k] = wv[5 * t + k];
+    for (int k = 0; k < 10; ++k) x[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xs), k));
     float v[8];
     float s = 0.f;
 #pragma unroll

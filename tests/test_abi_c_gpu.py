@@ -112,10 +112,10 @@ def test_two_rank_bench_on_one_gpu_matches_single_process(tmp_path):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for rank in range(2):
-        # FDM_BENCH_TAKE_TURNS: the two ranks share this box's ONE GPU; their device work takes turns (two HuBERT-large encoders
-        # co-running on one device are not bit-reproducible: DESIGN.md section 7, known issue).  Ranks on their own GPUs never do.
+        # (the two ranks co-run on this box's ONE GPU: this leg is what exposed the scalar-cache hazard of round 4's conv 0 kernel --
+        #  two encoders sharing a device -- fixed in round 5)
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   FDM_DIST_BACKEND="gloo", FDM_BENCH_TAKE_TURNS="1")
+                   FDM_DIST_BACKEND="gloo")
         procs.append(subprocess.Popen(common5 + ["--gpus", "2", "--batch", "2", "--dump", two5], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=1200) for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(o[0] + o[1] for o in outs)
