@@ -436,9 +436,10 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const fd
   constexpr int ROWB = KCH * 16;                 // bytes per LDS row
   constexpr int RPI = 1024 / ROWB;               // rows written by one wave-wide LDS-DMA instruction
   constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
-  // glds instructions (1 KB pieces) per wave, k-tile and plane.  A tile whose A pieces do not divide by the wave count (80 rows =
-  // 10 pieces on 8 waves) deals them out strided -- piece i * NW + wave -- and the first NA % NW waves carry one more: their
-  // counted waits use their own piece count (a wave-uniform branch).
+  // glds instructions (1 KB pieces) per ISSUING wave (IW of them: the LW loader waves, or every wave of the lockstep loop), k-tile
+  // and plane.  A tile whose A pieces do not divide by IW (80 rows = 10 pieces on 4 loaders / 8 waves) deals them out strided --
+  // piece i * IW + wave -- and the first NA % IW issuing waves carry one more: their counted waits use their own piece count (a
+  // wave-uniform branch).
   constexpr int NA = BM / RPI, NWP = BN / RPI;
   constexpr int IW = LW > 0 ? LW : NW;          // waves that issue the tile loads: the loader waves, or every wave
   constexpr bool UNEVEN = NA % IW != 0;
