@@ -1088,6 +1088,15 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
   const long long t128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128) * batch;
   const long long t128x64 = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * batch;
   const long long t64 = (long long)((a.M + 63) / 64) * ((a.N + 63) / 64) * batch;
+  const long long t64x128 = (long long)((a.M + 63) / 64) * ((a.N + 127) / 128) * batch;
+  // Round 5 (the loop runs at the CU's L2 -> LDS rate: fewer bytes on the busiest CU wins; rules from the tuner's picks over 66 shapes on
+  // the loader-wave build, profiles/r5_tile_sweep/):
+  //  * narrow outputs (N <= 512: MEAD's out-proj / FFN2 / decoder at 2400-4000 rows) whose 64x64 grid needs two workgroups per CU or two
+  //    rounds while the 64x128 grid is one round: 64x128 (-4...-8 % on those chains)
+  const bool narrow_one_round = elem_bytes == 2 && a.N <= 512 && a.N % 128 == 0 && t64 > 256 && t64x128 <= 256;
+  //  * a few hundred rows and a wide projection whose 128x64 grid is (nearly) one round: 128x64 instead of two co-resident 64x64 tiles
+  //    per CU (QKV at 400-600 rows, FFN1 at 600: -2.5...-4 %)
+  const bool wide_128x64 = elem_bytes == 2 && a.M <= 1024 && a.N >= 2048 && t128x64 >= 160 && t128x64 <= 256;
   if (!split) {
     // Measured on MI355X (profiles/README.md): the biggest tile wins only once it still yields >= 2 blocks per CU;
     // below that the 64x64 tile's extra blocks beat its higher L2->LDS traffic.
@@ -1101,9 +1110,20 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
     // against 33.3 on the 512 tiles of 128x128, profiles/r4_pmc_hubert; the lockstep 256x128 kernel of rounds 2-4 measured 29.9 against
     // 29.4 for the ping-pong loop there and is retired: profiles/r5_xcd_band/gemm_tiles_hubert_ffn.txt)
     if (elem_bytes == 2 && a.M > 1024 && t128 >= thr128 && gemm_one_round(t256)) return FDM_TILE_256x128_PP;
-    if (t128 >= thr128) return FDM_TILE_128x128;
+    if (t128 >= thr128) {
+      // 128x128 unless its last round is less than half full (600 tiles = 2.34 rounds: QKV at 3200 rows, MEAD's at 6400): 128x64 on the
+      // 3-stage ring, two workgroups per CU, balances that tail (-4 % on those chains)
+      const long long tail = t128 % 256;
+      if (elem_bytes == 2 && t128 < 1024 && tail > 0 && tail < 128) return FDM_TILE_128x64;
+      return FDM_TILE_128x128;
+    }
     if (gemm_one_round_80(a)) return FDM_TILE_80x128;
     if (elem_bytes == 2 && gemm_one_round_64x128(a)) return FDM_TILE_64x128;
+    if (wide_128x64) return FDM_TILE_128x64;
+    if (narrow_one_round && a.M > 1024) return FDM_TILE_64x128;
+    // one short clip (and MEAD's d = 512 sites up to ~800 rows): 64x64 tiles leave most CUs idle -> 32-row tiles, twice the workgroups
+    // (the split kinds have had this rule since round 3; with loader waves it pays in bf16 too: -3.5...-5.5 % on MEAD's chains at 200-800 rows)
+    if (elem_bytes == 2 && t64 <= 128 && a.N <= 1536) return FDM_TILE_32x64_S3;
     // (measured in bf16 only: the fp32 kind keeps its rules; short-K products whose 64x64 grid is resident in one round -- two
     //  64 KB rings per CU -- stay on it: MEAD's d = 512 sites at 1200-1600 rows lost 3-5 % on larger tiles)
     if (elem_bytes == 2 && a.M > 1024 && (t64 > 512 || a.K >= 1024)) {
@@ -1120,13 +1140,29 @@ static int gemm_heuristic_tile(const fdm_gemm_args& a, int elem_bytes, bool spli
   if (t128 >= 512) return FDM_TILE_128x128;
   if (gemm_one_round_80(a)) return FDM_TILE_80x128;
   if (gemm_one_round_64x128(a)) return FDM_TILE_64x128;
+  if (wide_128x64) return FDM_TILE_128x64;
   if (a.M > 1024) {            // the tuner's picks at 1100..4000 rows as rules (see above)
     if (gemm_one_round(t128)) return FDM_TILE_128x128;
+    if (narrow_one_round) return FDM_TILE_64x128;
     if (t128x64 > 128 && t128x64 <= 256) return FDM_TILE_128x64;     // (split kinds: 3-stage, 144 KB ring -- one per CU, so one round only)
+    // Beyond the rules (1600+ rows in the split kinds, where every ring is one workgroup per CU): the tile with the fewest operand rows on
+    // the busiest CU, rounds x (BM + BN) -- the model the tuner prunes with; it reproduces the tuner's picks at 1600-4800 rows (80x128 for
+    // QKV at 1600 and FFN1 at 2400, 128x128 for QKV at 2400: -3.6...-8.6 % on those chains)
+    struct { int id, bm, bn; } cand[] = {{FDM_TILE_64x64, 64, 64}, {FDM_TILE_128x64, 128, 64}, {FDM_TILE_64x128, 64, 128}, {FDM_TILE_80x128, 80, 128}, {FDM_TILE_128x128, 128, 128}};
+    int best = FDM_TILE_64x64; long long best_rows = -1;
+    for (auto& c : cand) {
+      if (a.N % c.bn) continue;
+      const long long tiles = (long long)((a.M + c.bm - 1) / c.bm) * (a.N / c.bn) * batch;
+      const long long rows = ((tiles + 255) / 256) * (c.bm + c.bn);
+      if (best_rows < 0 || rows < best_rows) { best = c.id; best_rows = rows; }
+    }
+    return best;
   } else {
     // a single short clip: 64x64 tiles leave half the CUs idle -> 32-row tiles (72 KB rings, two per CU); 257..512 tiles of a
     // wide projection: the 2-stage ring (64 KB) keeps all of them resident in one round instead of two
     if (t64 <= 128) return FDM_TILE_32x64_S3;
+    // more than one round of 64x64 tiles (one 128 KB ring per CU) where the 64x128 grid is a single round: MEAD's QKV at 800 rows (-6...-8 %)
+    if (t64 > 256 && t64x128 <= 256 && a.N % 128 == 0) return FDM_TILE_64x128;
     if (t64 > 256 && t64 <= 512 && a.N >= 2048) return FDM_TILE_64x64_S2;
   }
   if (t128x64 >= 700) return FDM_TILE_128x64;
@@ -1154,7 +1190,7 @@ static hipError_t gemm_sched_fuse_launch(const fdm_gemm_args& a, hipStream_t s) 
 
 // K-sliced launches (fdm_gemm_args.ksplit): the 64-column tiles, ring depth by tile id.  With S slices per output tile the grid
 // is S times as large and a slice's chain 1 / S as long, so shallower rings (more co-resident slices per CU) are the candidates.
-static int gemm_ksplit_heuristic_tile(const fdm_gemm_args& a) { return a.M <= 128 ? FDM_TILE_32x64_S3 : FDM_TILE_64x64; }   // (profiles/r5_splitk/)
+static int gemm_ksplit_heuristic_tile(const fdm_gemm_args& a) { return a.M <= 256 ? FDM_TILE_32x64_S3 : FDM_TILE_64x64; }   // (profiles/r5_splitk/; the tuner's pick at 249 rows on the loader-wave build)
 template <typename T>
 static hipError_t gemm_dispatch_ksplit(const fdm_gemm_args& a, int tile_id, hipStream_t s) {
   switch (tile_id > 0 ? tile_id : gemm_ksplit_heuristic_tile(a)) {

@@ -234,17 +234,20 @@ def test_tile_heuristic_is_a_pure_function_of_the_shape():
     assert tile(B, 800, 3072, 1024) == _lib.TILE_80x128 and tile(S, 800, 3072, 1024) == _lib.TILE_80x128 and tile(F, 800, 3072, 1024) == _lib.TILE_80x128
     assert tile(B, 800, 1024, 1024) == _lib.TILE_64x64 and tile(B, 800, 1024, 2048) == _lib.TILE_64x64
     assert tile(B, 800, 2048, 1024) == _lib.TILE_64x128 and tile(S, 800, 2048, 1024) == _lib.TILE_64x128 and tile(F, 800, 2048, 1024) == _lib.TILE_64x64      # FFN1: 13 x 16 = 208 tiles, one round
-    assert tile(B, 100, 1024, 1024) == _lib.TILE_64x64 and tile(S, 100, 1024, 1024) == _lib.TILE_32x64_S3
-    assert tile(S, 600, 3072, 1024) == _lib.TILE_64x128 and tile(S, 400, 3072, 1024) == _lib.TILE_64x64_S2 and tile(S, 800, 1024, 1024) == _lib.TILE_64x64      # 10 x 24 = 240 one-round tiles | 7 x 48 = 336 tiles on the 2-stage ring
+    assert tile(B, 100, 1024, 1024) == _lib.TILE_32x64_S3 and tile(S, 100, 1024, 1024) == _lib.TILE_32x64_S3 and tile(B, 200, 512, 512) == _lib.TILE_32x64_S3      # one short clip: 32-row tiles
+    assert tile(S, 600, 3072, 1024) == _lib.TILE_64x128 and tile(S, 400, 3072, 1024) == _lib.TILE_128x64 and tile(B, 400, 3072, 1024) == _lib.TILE_128x64 and tile(S, 800, 1024, 1024) == _lib.TILE_64x64      # 10 x 24 = 240 one-round tiles | 4 x 48 = 192 tiles of 128x64: (nearly) one round
     assert tile(B, 1992, 2048, 1024) == _lib.TILE_128x128 and tile(S, 1992, 2048, 1024) == _lib.TILE_128x128      # 16 x 16 = 256 tiles
     assert tile(B, 2400, 3072, 1024) == _lib.TILE_256x128_PP                                                         # 10 x 24 = 240 tiles
     assert tile(B, 1200, 1024, 1024) == _lib.TILE_128x64 and tile(B, 3000, 1024, 1024) == _lib.TILE_128x64 and tile(B, 3200, 1024, 1024) == _lib.TILE_128x128
-    assert tile(S, 1200, 1024, 1024) == _lib.TILE_128x64 and tile(S, 2400, 2048, 1024) == _lib.TILE_64x64
+    assert tile(S, 1200, 1024, 1024) == _lib.TILE_128x64 and tile(S, 2400, 2048, 1024) == _lib.TILE_80x128      # (beyond the rules: fewest operand rows on the busiest CU)
     assert tile(B, 1200, 512, 512) == _lib.TILE_64x64                   # MEAD's short-K sites stay on the resident 64x64 grid
     assert tile(F, 1992, 2048, 1024) == _lib.TILE_64x64 and tile(F, 1200, 1024, 1024) == _lib.TILE_64x64
-    assert tile(B, 6400, 3072, 1024) == _lib.TILE_128x128 and tile(S, 6400, 1024, 2048) == _lib.TILE_128x64
+    assert tile(B, 6400, 3072, 1024) == _lib.TILE_128x128 and tile(S, 6400, 1024, 2048) == _lib.TILE_128x128
     assert tile(B, 6400, 1024, 2048) == _lib.TILE_256x128_PP and tile(B, 3200, 2048, 1024) == _lib.TILE_256x128_PP      # thousands of rows: the ping-pong loop
     assert tile(B, 6400, 1024, 1024, sched_fuse=1) == _lib.TILE_256x128_PP and tile(F, 6400, 1024, 1024, sched_fuse=1) == _lib.TILE_64x64
     assert tile(B, 2400, 1024, 1024) == _lib.TILE_80x128                # 30 x 8 = 240 tiles
     assert tile(B, 800, 1024, 1024, sched_fuse=1) == _lib.TILE_64x64
     assert tile(B, 100, 1024, 1024, batch=8) == _lib.TILE_64x64
+    # round 5 (loader-wave build, profiles/r5_tile_sweep/): a half-empty last round of 128x128 -> 128x64; narrow outputs on one round of 64x128
+    assert tile(B, 3200, 3072, 1024) == _lib.TILE_128x64 and tile(B, 2400, 512, 1024) == _lib.TILE_64x128 and tile(S, 800, 1536, 512) == _lib.TILE_64x128
+    assert tile(S, 1600, 3072, 1024) == _lib.TILE_80x128 and tile(S, 2400, 3072, 1024) == _lib.TILE_128x128
