@@ -289,3 +289,21 @@ def test_checkpoint_files_round_trip(tmp_path):
     o0, _ = pipeline.animate(d0, ae0, wav, ddim_steps=5, seed=3, device=DEV)
     o1, _ = pipeline.animate(d1, ae1, wav, ddim_steps=5, seed=3, device=DEV)
     assert o0.shape[0] == 1 and torch.isfinite(o0).all() and torch.equal(o0, o1)
+
+
+def test_single_clip_models_set_the_plan_and_stay_inside_the_contract():
+    """pipeline.build_models(single_clip=True) -- what the sampler entry points use at batch size 1 -- puts the K-slice setting on the
+    denoiser's plan (and on every plan the module rebuilds); the animated clip stays within fp32 rounding of the plain setting."""
+    from fdm_amd import pipeline
+    from fdm_amd.modules import SINGLE_CLIP_PLAN
+    wav = pipeline.processor_normalize((torch.randn(32000, generator=torch.Generator().manual_seed(3)) * 0.1).numpy(), pad_seconds=0)
+    outs = []
+    for single in (False, True):
+        diffusion, ae = pipeline.build_models("mead", device=DEV, dtype="f16x3", cfg_level=2.5, single_clip=single)
+        model = diffusion.denoise_fn.model
+        v, lat = pipeline.animate(diffusion, ae, torch.from_numpy(wav).unsqueeze(0), seed=5, device=DEV)
+        plan = model.plan(torch.device(DEV))
+        assert (plan.get("ksplit.out"), plan.get("ksplit.ffn2")) == ((SINGLE_CLIP_PLAN["ksplit.out"], SINGLE_CLIP_PLAN["ksplit.ffn2"]) if single else (1, 1))
+        outs.append(lat.cpu())
+    assert torch.isfinite(outs[1]).all() and float((outs[0] - outs[1]).abs().max()) < 1e-3      # 1000 DDPM steps apart by fp32 rounding only
+
