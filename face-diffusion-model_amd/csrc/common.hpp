@@ -59,15 +59,32 @@ struct f16x3_t {};
 template <typename T> struct Opnd { using E = T; using KV = T; static constexpr int NP = 1; static constexpr float SCALE = 1.f; };
 template <> struct Opnd<f16x3_t> { using E = f16; using KV = f16x3_t; static constexpr int NP = 2; static constexpr float SCALE = 2048.f; };
 
+// Result stores are agent-scope write-through (`sc1`): the line goes to the memory side as it is written instead of sitting dirty in
+// the storing XCD's L2 until the end-of-kernel release writes it back.  Every launch of the step program is followed by a launch that
+// reads its output from other XCDs, so that write-back is on the launch-to-launch path: cfg2 +2.0 % in both modes, cfg3 +4.5...5 %, cfg4
+// +1.4...2.7 %, single clips +0.6...2.7 %, cfg5 (1992 rows) -0.2...-0.7 %, HuBERT 0...+1.7 % (same box, alternating;
+// profiles/r5_store_policy/).  `sc0 sc1` measures the same; `nt` (with or without the scope bits) is 13 % slower.  Cache policy only:
+// the bytes stored are the same.
+__device__ __forceinline__ void st16(void* p, const f32x4& v) {
+  // (a VMEM store of more than 64 bits needs 2 wait states before a VALU write to its data registers on gfx940+; the compiler's
+  //  hazard recogniser does not see into the asm, so the wait states travel with the store)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+template <typename V8> __device__ __forceinline__ void st8(void* p, const V8& v) {
+  static_assert(sizeof(V8) == 8, "st8 stores 8 bytes");
+  typedef __attribute__((ext_vector_type(2))) int i2;
+  const i2 w = __builtin_bit_cast(i2, v);
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+}
 // Store 4 consecutive fp32 values v as operand kind T at dst (split kinds: hi plane at dst, lo plane at dst + lo_off).
 template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, long long lo_off, const f32x4& v) {
   using E = typename Opnd<T>::E;
   if constexpr (std::is_same<T, float>::value) {
-    *(f32x4*)dst = v;
+    st16(dst, v);
   } else if constexpr (Opnd<T>::NP == 1) {
     typedef __attribute__((ext_vector_type(4))) E e4;
     e4 o = {(E)v[0], (E)v[1], (E)v[2], (E)v[3]};
-    *(e4*)dst = o;
+    st8(dst, o);
   } else {
     typedef __attribute__((ext_vector_type(4))) E e4;
     e4 h, l;
@@ -78,8 +95,8 @@ template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, lon
       h[j] = (E)x;
       l[j] = (E)((x - (float)h[j]) * Opnd<T>::SCALE);
     }
-    *(e4*)dst = h;
-    *(e4*)((E*)dst + lo_off) = l;
+    st8(dst, h);
+    st8((E*)dst + lo_off, l);
   }
 }
 template <typename T> __device__ __forceinline__ void store_opnd1(void* dst, long long lo_off, float v) {

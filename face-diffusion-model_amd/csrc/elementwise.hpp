@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
   }
-  if (p.y_f32) *(f32x4*)(p.y_f32 + (size_t)row * d + col) = y;
+  if (p.y_f32) st16(p.y_f32 + (size_t)row * d + col, y);
   if (p.y_t) store_opnd4<T>((typename Opnd<T>::E*)p.y_t + (size_t)row * d + col, p.y_t_lo_off, y);
 }
 

@@ -264,7 +264,7 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
           for (int j = 0; j < 4; ++j) store_opnd1<KK>(okp + (size_t)h * kv_blk + vp_offset<KV>(kv_l, e2 + j, p.kv_hd), p.kv_lo_off, v[j]);
           continue;
         }
-        if (o32) *(f32x4*)(o32 + ni * 16) = v;
+        if (o32) st16(o32 + ni * 16, v);
         if (ot) store_opnd4<T>(ot + ni * 16, p.out_t_lo_off, v);
       }
     }
