@@ -47,7 +47,10 @@ template <typename T> __device__ __forceinline__ float fexp(float x) {
 template <typename T, int HD> constexpr bool attn_streamed() { return Opnd<T>::NP == 2 && HD == 256; }
 
 template <typename T, int HD, int QS>
-__global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_kernel(const fdm_attn_args p) {
+__global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_kernel(const void* pQ, const void* pKp, const void* pVp, int p_q_lo_off, int p_kv_lo_off, int pL, int pB, int pH, int p_ldq,
+                                                                                     int pLpad, const fdm_attn_args p) {
+  // (the leading arguments repeat fields of p: kernel-argument preload, 13 SGPRs -- the Q / K fragment loads go out without waiting for
+  //  the argument block; see gemm_glds_kernel.  The plane offsets travel as 32-bit element counts: attn_launch_t checks them.)
   // QS = 16-query sub-tiles per workgroup (1 or 2).  With QS = 2 every K / V^T fragment fetched from L2 feeds
   // two S^T and two O^T products: the kernel is bound by L2 -> register fragment traffic, which this halves.
   using E = typename Opnd<T>::E;
@@ -68,22 +71,22 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   // decoded such that all query tiles of one (clip, head) land on ONE XCD -- its K / V block is then fetched into one
   // L2 instead of eight (FETCH_SIZE showed ~2.3x the algorithmic bytes with the plain (tile, head, clip) grid) -- and
   // the longest (last, causal) query tiles are dispatched first.
-  const int L = p.L;
+  const int L = pL;
   const int nqt = (L + BQ - 1) / BQ;
   const int grp = blockIdx.x / (8 * nqt), rem = blockIdx.x % (8 * nqt);
   const int bh = grp * 8 + (rem & 7);
-  if (bh >= p.B * p.H) return;
-  const int b = bh / p.H, h = bh - b * p.H;
+  if (bh >= pB * pH) return;
+  const int b = bh / pH, h = bh - b * pH;
   const int q0 = (nqt - 1 - (rem >> 3)) * BQ;
   // (+4 floats per row: the merge writes below put 8 lanes on 8 consecutive rows at one column; without the pad they share
   //  a bank group -- SQ_LDS_BANK_CONFLICT was 79 % of this kernel's LDS cycles)
   __shared__ __attribute__((aligned(16))) float part_o[4][BQ][HD + 4];
   __shared__ float part_m[4][BQ], part_l[4][BQ];
 
-  const E* Q = (const E*)p.Q + (size_t)b * L * p.ldq + (size_t)h * HD;
-  const E* Kp = (const E*)p.Kp + (size_t)(b * p.H + h) * HD * p.Lpad + (size_t)lane * EPC;
-  const E* Vp = (const E*)p.Vp + (size_t)(b * p.H + h) * HD * p.Lpad + (size_t)lane * EPC;
-  const size_t q_lo = NP == 2 ? (size_t)p.q_lo_off : 0, kv_lo = NP == 2 ? (size_t)p.kv_lo_off : 0;
+  const E* Q = (const E*)pQ + (size_t)b * L * p_ldq + (size_t)h * HD;
+  const E* Kp = (const E*)pKp + (size_t)(b * pH + h) * HD * pLpad + (size_t)lane * EPC;
+  const E* Vp = (const E*)pVp + (size_t)(b * pH + h) * HD * pLpad + (size_t)lane * EPC;
+  const size_t q_lo = NP == 2 ? (size_t)p_q_lo_off : 0, kv_lo = NP == 2 ? (size_t)p_kv_lo_off : 0;
 
   int qi[QS];                              // this lane's query index in each sub-tile
   u32x4 qf[QS][NKS][NP];
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-      for (int pl = 0; pl < NP; ++pl) qf[u][ks][pl] = *(const u32x4*)(Q + pl * q_lo + (size_t)qrow * p.ldq + (ks * 4 + g) * EPC);
+      for (int pl = 0; pl < NP; ++pl) qf[u][ks][pl] = *(const u32x4*)(Q + pl * q_lo + (size_t)qrow * p_ldq + (ks * 4 + g) * EPC);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       o[u][c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -321,6 +324,7 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   }
 }
 
+#define ATTN_PRELOAD_ARGS a.Q, a.Kp, a.Vp, (int)a.q_lo_off, (int)a.kv_lo_off, a.L, a.B, a.H, (int)a.ldq, a.Lpad
 template <typename T, int HD>
 static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   // two query sub-tiles per workgroup once the sequence is long enough that halving the K / V traffic matters more
@@ -330,12 +334,12 @@ static void attn_launch_t(const fdm_attn_args& a, hipStream_t s) {
   if constexpr (HD <= 128 && Opnd<T>::NP == 1) {
     if (a.L >= qs2) {
       dim3 grid((a.L + 31) / 32 * groups);
-      hipLaunchKernelGGL((attn_kernel<T, HD, 2>), grid, dim3(256), 0, s, a);
+      hipLaunchKernelGGL((attn_kernel<T, HD, 2>), grid, dim3(256), 0, s, ATTN_PRELOAD_ARGS, a);
       return;
     }
   }
   dim3 grid((a.L + 15) / 16 * groups);
-  hipLaunchKernelGGL((attn_kernel<T, HD, 1>), grid, dim3(256), 0, s, a);
+  hipLaunchKernelGGL((attn_kernel<T, HD, 1>), grid, dim3(256), 0, s, ATTN_PRELOAD_ARGS, a);
 }
 
 template <typename T>

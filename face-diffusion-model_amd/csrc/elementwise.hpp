@@ -17,7 +17,11 @@ namespace fdm {
 // and is templated out of the step's instances: the inlined libm forms were 90 % of that kernel's code.)
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NV, bool HEAVY>
-__global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
+__global__ __launch_bounds__(64 * NV) void ln_row_kernel(const float* p_x, const float* p_add_mat, const float* p_add_tab, const int* p_tab_step,
+                                                         const int* p_tab_index, int p_add_mat_group, int p_add_mat_wrap, int p_add_mat_L,
+                                                         const fdm_ln_args p) {
+  // (the leading arguments repeat fields of p: kernel-argument preload, 13 SGPRs -- what the row, the matrix addend and the table row's
+  //  dependent loads need goes out without waiting for the argument block; see gemm_glds_kernel)
   __shared__ float red[4][NV];
   constexpr int d = 256 * NV;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -27,29 +31,29 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
   // go out at once, the table row one dependent scalar load (the device-side step word) later -- one memory latency in
   // all instead of one per operand (the kernel is launch-to-launch latency, not bandwidth)
   const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 v = *(const f32x4*)(p.x + (size_t)row * d + col);
+  f32x4 v = *(const f32x4*)(p_x + (size_t)row * d + col);
   // split-K partial planes of the row (fdm_gemm_args.ksplit): requested with everything else, summed in plane order below
   const int npl = p.x_planes;
   f32x4 vpl[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) vpl[i] = (i + 1 < npl) ? *(const f32x4*)(p.x + (size_t)(i + 1) * p.x_plane_stride + (size_t)row * d + col) : zero;
-  const bool has_e = p.add_mat || p.add_tab;
+  for (int i = 0; i < 3; ++i) vpl[i] = (i + 1 < npl) ? *(const f32x4*)(p_x + (size_t)(i + 1) * p.x_plane_stride + (size_t)row * d + col) : zero;
+  const bool has_e = p_add_mat || p_add_tab;
   int arow = row;                      // (uniform: scalar arithmetic) conditions of a clip share the clip's addend rows
-  if (p.add_mat_group > 0) {
-    const int m = p.add_mat_wrap > 0 ? row % p.add_mat_wrap : row;
-    arow = (m / p.add_mat_group) * p.add_mat_L + m % p.add_mat_L;
+  if (p_add_mat_group > 0) {
+    const int m = p_add_mat_wrap > 0 ? row % p_add_mat_wrap : row;
+    arow = (m / p_add_mat_group) * p_add_mat_L + m % p_add_mat_L;
   }
-  const f32x4 em = p.add_mat ? *(const f32x4*)(p.add_mat + (size_t)arow * d + col) : zero;
+  const f32x4 em = p_add_mat ? *(const f32x4*)(p_add_mat + (size_t)arow * d + col) : zero;
   const f32x4 g1 = *(const f32x4*)(p.gamma + col), b1 = *(const f32x4*)(p.beta + col);
   const float *gp2 = two ? p.gamma2 : p.gamma, *bp2 = two ? p.beta2 : p.beta;      // (a select of pointers, not of loaded data)
   const f32x4 g2 = *(const f32x4*)(gp2 + col), b2 = *(const f32x4*)(bp2 + col);
   f32x4 et = zero;
-  if (p.add_tab) {
-    const int k = p.tab_step ? *p.tab_step : 0;
-    const int idx = p.tab_index ? p.tab_index[k] : k;
-    et = *(const f32x4*)(p.add_tab + (size_t)idx * d + col);
+  if (p_add_tab) {
+    const int k = p_tab_step ? *p_tab_step : 0;
+    const int idx = p_tab_index ? p_tab_index[k] : k;
+    et = *(const f32x4*)(p_add_tab + (size_t)idx * d + col);
   }
-  const f32x4 e = p.add_tab ? em + et : em;
+  const f32x4 e = p_add_tab ? em + et : em;
   auto block_sum = [&](float x, int slot) {
     x = wave_sum(x);
     if (lane == 0) red[slot][wave] = x;
@@ -87,14 +91,15 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const fdm_ln_args p) {
   if (p.y_t) store_opnd4<T>((typename Opnd<T>::E*)p.y_t + (size_t)row * d + col, p.y_t_lo_off, y);
 }
 
+#define LN_PRELOAD_ARGS a.x, a.add_mat, a.add_tab, a.tab_step, a.tab_index, a.add_mat_group, a.add_mat_wrap, a.add_mat_L
 template <typename T, bool HEAVY>
 static hipError_t ln_launch_h(const fdm_ln_args& a, hipStream_t s) {
   dim3 grid(a.M);
   switch (a.d) {
-    case 256: hipLaunchKernelGGL((ln_row_kernel<T, 1, HEAVY>), grid, dim3(64), 0, s, a); break;
-    case 512: hipLaunchKernelGGL((ln_row_kernel<T, 2, HEAVY>), grid, dim3(128), 0, s, a); break;
-    case 768: hipLaunchKernelGGL((ln_row_kernel<T, 3, HEAVY>), grid, dim3(192), 0, s, a); break;
-    case 1024: hipLaunchKernelGGL((ln_row_kernel<T, 4, HEAVY>), grid, dim3(256), 0, s, a); break;
+    case 256: hipLaunchKernelGGL((ln_row_kernel<T, 1, HEAVY>), grid, dim3(64), 0, s, LN_PRELOAD_ARGS, a); break;
+    case 512: hipLaunchKernelGGL((ln_row_kernel<T, 2, HEAVY>), grid, dim3(128), 0, s, LN_PRELOAD_ARGS, a); break;
+    case 768: hipLaunchKernelGGL((ln_row_kernel<T, 3, HEAVY>), grid, dim3(192), 0, s, LN_PRELOAD_ARGS, a); break;
+    case 1024: hipLaunchKernelGGL((ln_row_kernel<T, 4, HEAVY>), grid, dim3(256), 0, s, LN_PRELOAD_ARGS, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

@@ -112,6 +112,7 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (split && a->out_t && a->out_t_lo_off <= 0) return fail(FDM_ERR_ARG, "gemm: split out_t needs out_t_lo_off");
   if (a->K % bk) return fail(FDM_ERR_SHAPE, "gemm: K=%d not a multiple of %d", a->K, bk);
   if (a->lda % epc || a->ldw % epc || !aligned16(a->A) || !aligned16(a->W)) return fail(FDM_ERR_ARG, "gemm: operands need 16-byte aligned rows");
+  if (a->lda < 0 || a->ldw < 0 || a->lda > 0x7fffffffLL || a->ldw > 0x7fffffffLL) return fail(FDM_ERR_SHAPE, "gemm: lda / ldw are passed to the kernel as 32-bit element counts");
   if (a->a_batch_stride % epc || a->w_batch_stride % epc) return fail(FDM_ERR_ARG, "gemm: batch strides need 16-byte alignment");
   if (!a->out_f32 && !a->out_t && !a->out_vp && !a->out_kp) return fail(FDM_ERR_ARG, "gemm: no output");
   if (a->out_kp || a->out_vp) {
@@ -182,6 +183,8 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream) {
     return fail(FDM_ERR_ARG, "attention: o_split needs dtype FDM_F32, a split kind and o_lo_off");
   if (a->dtype == FDM_F16X3 && (a->q_lo_off <= 0 || a->kv_lo_off <= 0 || a->o_lo_off <= 0 || a->q_lo_off % 8 || a->kv_lo_off % 8 || a->o_lo_off % 4))
     return fail(FDM_ERR_ARG, "attention: split operands need q_lo_off, kv_lo_off and o_lo_off");
+  if (a->q_lo_off > 0x7fffffffLL || a->kv_lo_off > 0x7fffffffLL || a->ldq > 0x7fffffffLL)
+    return fail(FDM_ERR_SHAPE, "attention: q_lo_off, kv_lo_off and ldq are passed to the kernel as 32-bit element counts");
   const int epc = a->dtype == FDM_F32 ? 4 : 8;
   if (a->ldq % epc || a->ldo % 4 || !aligned16(a->Q) || !aligned16(a->Kp) || !aligned16(a->Vp) || !aligned16(a->O))
     return fail(FDM_ERR_ARG, "attention: operands need 16-byte aligned rows");

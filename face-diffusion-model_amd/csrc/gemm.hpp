@@ -428,7 +428,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // the loop runs at the L2 -> LDS rate of the CU instead of at the sum of its phases.  Same LDS image, same k order, same
 // epilogue: bit-identical to LW = 0 (FDM_TILE_LOCKSTEP selects it for A/B and tests).
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KCH = 8, bool HEAVY = false, bool SCHED = false, int SPEC = 0, int LW = 0>
-__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const fdm_gemm_args p) {
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const void* pA, const void* pW, long long p_a_lo_off, long long p_w_lo_off,
+                                                                        int pM, int pN, int pK, int p_lda, int p_ldw, const fdm_gemm_args p) {
+  // The nine leading arguments repeat fields of p: they are the 13 SGPRs of kernel-argument PRELOAD (the build passes
+  // -amdgpu-kernarg-preload-count=13; gfx950 fills them at wave launch), everything the first tile requests need -- so the first
+  // LDS-DMA instructions go out without waiting for a scalar load of the argument block (cold at every launch: ~0.5 us).
   // KCH = 16-byte chunks of K per LDS row: 8 (128-B rows) or 16 (256-B rows: half the barriers per K)
   using E = typename Opnd<T>::E;
   constexpr int NP = Opnd<T>::NP;                // operand planes (2 for the split kinds: hi, lo)
@@ -456,11 +460,6 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const fd
   float* rowstat = (float*)(smem + NST * STAGE);      // LayerNorm-folding scratch behind the ring
 
   const int tid = threadIdx.x, lane = tid & 63;
-  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-    const int nv = *p.incr_counter + 1;
-    *p.incr_counter = nv;
-    if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
-  }
 #ifdef FDM_GEMM_STAMPS
   unsigned long long* stamps = (!p.incr_counter && p.incr_table) ? (unsigned long long*)p.incr_table + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
   if (stamps && tid == 0) { stamps[0] = wall_clock64(); stamps[5] = t_first; }
@@ -493,11 +492,15 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const fd
     by = r2 / nx; bx = r2 - by * nx;
   }
   const int m0 = by * BM, n0 = bx * BN;
-  const int M = p.M, N = p.N;
+  const int M = pM, N = pN;
   constexpr int EPC = 16 / (int)sizeof(E);
-  int nk = p.K / (KCH * EPC);
-  const E* A = (const E*)p.A + (size_t)z * p.a_batch_stride;
-  const E* W = (const E*)p.W + (size_t)z * p.w_batch_stride;
+  int nk = pK / (KCH * EPC);
+  const E* A = (const E*)pA;
+  const E* W = (const E*)pW;
+  if (z) {                                       // (unbatched launches -- the step's -- do not touch the argument block before their first requests)
+    A += (size_t)z * p.a_batch_stride;
+    W += (size_t)z * p.w_batch_stride;
+  }
   if constexpr (KSP) {                           // this slice's k-tiles: [slice * nk, (slice + 1) * nk)
     nk /= p.ksplit;
     A += (size_t)blockIdx.z * nk * (KCH * EPC);
@@ -506,7 +509,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const fd
   if constexpr (B2) A += (size_t)c2 * p.a_batch_stride2;
   const KSliceArgs<KSP ? 1 : (B2 ? 2 : 0)> ksa(p, KSP ? (int)blockIdx.z : c2, (int)sizeof(E));
   const fdm_gemm_args& pe = ksa.a;               // what the epilogue reads (bias, residual, outputs)
-  const size_t a_lo = (size_t)p.a_lo_off * sizeof(E), w_lo = (size_t)p.w_lo_off * sizeof(E);   // bytes hi plane -> lo plane
+  const size_t a_lo = (size_t)p_a_lo_off * sizeof(E), w_lo = (size_t)p_w_lo_off * sizeof(E);   // bytes hi plane -> lo plane
 
   // per-lane source pointers (k-tile 0, plane 0); LDS row groups are wave-uniform.  The LDS image is
   // lane-linear, so the swizzle sits on the source: lane (row, slot) fetches chunk slot ^ (row % KCH).
@@ -517,12 +520,12 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const fd
   for (int i = 0; i < A_IPW; ++i) {
     const int piece = UNEVEN ? min(i * IW + wave, NA - 1) : wave * A_IPW + i;
     const int row = RPI * piece + lrow;
-    a_src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * p.lda) + ((slot ^ (row % KCH)) << 4);
+    a_src[i] = (const char*)(A + (size_t)min(m0 + row, M - 1) * p_lda) + ((slot ^ (row % KCH)) << 4);
   }
 #pragma unroll
   for (int i = 0; i < W_IPW; ++i) {
     const int row = RPI * (wave * W_IPW + i) + lrow;
-    w_src[i] = (const char*)(W + (size_t)min(n0 + row, N - 1) * p.ldw) + ((slot ^ (row % KCH)) << 4);
+    w_src[i] = (const char*)(W + (size_t)min(n0 + row, N - 1) * p_ldw) + ((slot ^ (row % KCH)) << 4);
   }
   auto issue = [&](int kt) {
     char* sb = smem + (kt % NST) * STAGE;
@@ -562,6 +565,12 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const fd
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
       if (t < nk) issue(t);
+  }
+  // (the step counter's increment rides on one thread of the launch; after the first requests so that they do not wait for p)
+  if (p.incr_counter && tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+    const int nv = *p.incr_counter + 1;
+    *p.incr_counter = nv;
+    if (p.incr_table) p.incr_counter[1] = p.incr_table[nv];    // e.g. t = tseq[step]: saves later kernels one dependent load
   }
   if constexpr (LW > 0) {
     if (loader) {
@@ -960,7 +969,8 @@ static hipError_t gemm_glds_launch_h(const fdm_gemm_args& a, hipStream_t s) {
     return hipFuncSetAttribute((const void*)gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC, LW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) == hipSuccess;
   }();
   (void)once;
-  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC, LW>), grid, dim3(64 * (WM * WN + LW)), lds, s, a);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, BM, BN, WM, WN, NST, KCH, HEAVY, SCHED, SPEC, LW>), grid, dim3(64 * (WM * WN + LW)), lds, s,
+                     a.A, a.W, (long long)a.a_lo_off, (long long)a.w_lo_off, a.M, a.N, a.K, (int)a.lda, (int)a.ldw, a);
   return hipGetLastError();
 }
 // FDM_GEMM_LOCKSTEP=1 (env, read once): FDM_TILE_LOCKSTEP for every launch of the process -- A/B of the once-per-clip stages, whose
