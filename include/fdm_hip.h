@@ -105,7 +105,8 @@ int fdm_op_sched_step(const fdm_sched_args* a, void* stream);
  * and/or operand-dtype copies.  For a fused QKV projection the K columns [kp_col0, vp_col0) and the
  * V columns [vp_col0, N) can be written straight into the attention kernel's fragment-packed
  * buffers (see fdm_attn_args) instead of out_t/out_f32.  K must be a multiple of 32 (fp32) /
- * 64 (16-bit kinds); A, W 16-byte aligned with lda, ldw multiples of 4 (fp32) / 8 (16-bit kinds).   */
+ * 64 (16-bit kinds); A, W 16-byte aligned with lda, ldw multiples of 4 (fp32) / 8 (16-bit kinds), 0 <= lda, ldw < 2^31 (they reach
+ * the kernel as 32-bit preloaded arguments; FDM_ERR_SHAPE otherwise).   */
 typedef struct fdm_gemm_args {
   const void* A; long long lda; long long a_batch_stride;
   const void* W; long long ldw; long long w_batch_stride;
@@ -218,7 +219,7 @@ int fdm_gemm_heuristic_tile(const fdm_gemm_args* a);
  *   Vp[ (((kt*(hd/16) + e/16)*4 + g)*16 + e%16)*EPC + w%EPC ]        g = w / EPC
  * Written by fdm_op_gemm (out_kp / out_vp) or by fdm_op_pack_kv from row-major K, V.          */
 typedef struct fdm_attn_args {
-  const void* Q; long long ldq;
+  const void* Q; long long ldq;     /* ldq, q_lo_off, kv_lo_off < 2^31: 32-bit preloaded kernel arguments (FDM_ERR_SHAPE otherwise) */
   const void* Kp;
   const void* Vp; int Lpad;
   void* O; long long ldo;

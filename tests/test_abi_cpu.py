@@ -97,6 +97,8 @@ def test_argument_validation_of_the_round5_additions():
     assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"batch2" in l.fdm_last_error()
     a = args(); a.batch2, a.tile = 2, _lib.TILE_80x128
     assert l.fdm_op_gemm(C.byref(a), None) == -1 and b"batch2 runs on" in l.fdm_last_error()
+    a = args(); a.lda = 1 << 31                                              # row strides reach the kernel as 32-bit preloaded arguments
+    assert l.fdm_op_gemm(C.byref(a), None) == -2 and b"32-bit" in l.fdm_last_error()
     ln = _lib.LnArgs()
     ln.x, ln.gamma, ln.beta, ln.M, ln.d, ln.y_f32, ln.dtype = 16, 16, 16, 4, 256, 16, _lib.F32
     ln.x_planes, ln.x_plane_stride = 5, 4096
