@@ -24,6 +24,11 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const float* p_x, const
   //  dependent loads need goes out without waiting for the argument block; see gemm_glds_kernel)
   __shared__ float red[4][NV];
   constexpr int d = 256 * NV;
+#ifdef FDM_GEMM_STAMPS
+  // instrumented build (tools/coldstart_probe.cpp): with x_planes == 0 the stamp buffer rides in x_plane_stride (8 words per row)
+  const unsigned long long t_first = wall_clock64();
+  unsigned long long t_loaded = 0, t_reduced = 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int row = blockIdx.x, col = tid * 4;
   const bool two = p.gamma2 != nullptr;
@@ -67,6 +72,12 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const float* p_x, const
   for (int i = 0; i < 3; ++i)
     if (i + 1 < npl) v += vpl[i];
   if (!two && has_e) v += e;
+#ifdef FDM_GEMM_STAMPS
+  asm volatile("" ::"v"(v[0]), "v"(e[0]), "v"(g2[0]), "v"(b2[0]));
+  __builtin_amdgcn_sched_barrier(0);
+  t_loaded = wall_clock64();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   float mean = block_sum((v[0] + v[1]) + (v[2] + v[3]), 0) * (1.f / d);
   v -= mean;
   float var = block_sum((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]), 1) * (1.f / d);
@@ -80,6 +91,12 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const float* p_x, const
     rstd = 1.f / sqrtf(var + p.eps);
   }
   f32x4 y = v * rstd * g2 + b2;
+#ifdef FDM_GEMM_STAMPS
+  asm volatile("" ::"v"(y[0]));
+  __builtin_amdgcn_sched_barrier(0);
+  t_reduced = wall_clock64();
+  __builtin_amdgcn_sched_barrier(0);
+#endif
   if constexpr (HEAVY) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) y[j] = act_apply_t<T>(y[j], p.act);
@@ -89,6 +106,17 @@ __global__ __launch_bounds__(64 * NV) void ln_row_kernel(const float* p_x, const
   }
   if (p.y_f32) st16(p.y_f32 + (size_t)row * d + col, y);
   if (p.y_t) store_opnd4<T>((typename Opnd<T>::E*)p.y_t + (size_t)row * d + col, p.y_t_lo_off, y);
+#ifdef FDM_GEMM_STAMPS
+  if (p.x_planes == 0 && p.x_plane_stride) {
+    const unsigned long long t_issued = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long* st = (unsigned long long*)p.x_plane_stride + (size_t)row * 8;
+      st[5] = t_first; st[0] = t_first; st[1] = t_loaded; st[2] = t_reduced; st[3] = t_issued; st[4] = wall_clock64();
+    }
+  }
+#endif
 }
 
 #define LN_PRELOAD_ARGS a.x, a.add_mat, a.add_tab, a.tab_step, a.tab_index, a.add_mat_group, a.add_mat_wrap, a.add_mat_L

@@ -163,6 +163,7 @@ int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
     if (a->a_batch_stride2 % epc) return fail(FDM_ERR_ARG, "gemm: a_batch_stride2 needs 16-byte alignment");
     if (tl != 0 && tl != FDM_TILE_64x64 && tl != FDM_TILE_64x64_S2 && tl != FDM_TILE_128x64)
       return fail(FDM_ERR_ARG, "gemm: batch2 runs on the 64-column tiles (FDM_TILE_64x64, FDM_TILE_64x64_S2, FDM_TILE_128x64), not tile %d", tl);
+    if (a->batch < 1) return fail(FDM_ERR_ARG, "gemm: batch2 needs batch >= 1 (the group count of the second batch level)");
   }
   fdm_gemm_args c = *a;
   return submit([c](hipStream_t s) { return fdm::gemm_launch(c, s); }, stream, "gemm");

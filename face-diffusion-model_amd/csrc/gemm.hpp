@@ -476,7 +476,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const vo
     // second batch level: grid z = batch2 * batch.  Workgroups are dispatched in linear-id order round-robin over the 8 XCDs, so
     // id % 8 names the L2 a workgroup runs behind: deal the ids so that XCD x works on groups [x G / 8, (x + 1) G / 8) only,
     // group-major (all clips and row tiles of one group back to back): each L2 streams its share of W exactly once.
-    const int nx = gridDim.x, ny = gridDim.y, G = p.batch, C = p.batch2;
+    const int nx = gridDim.x, ny = gridDim.y, G = p.batch > 0 ? p.batch : 1, C = p.batch2;
     const int id = (blockIdx.z * ny + blockIdx.y) * nx + blockIdx.x;
     int g_, r;
     if (G % 8 == 0) {
@@ -1222,7 +1222,8 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
   }
   const int tile_id = a.tile & FDM_TILE_ID_MASK;
   if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
-  const int want = tile_id > 0 ? tile_id : gemm_tile_override();
+  // (FDM_GEMM_TILE forces one tile on the plain launches only: a second-batch-level launch runs on its own tile set -- like ksplit above)
+  const int want = tile_id > 0 ? tile_id : (a.batch2 >= 1 ? 0 : gemm_tile_override());
   switch (want > 0 ? want : gemm_heuristic_tile(a, (int)sizeof(typename Opnd<T>::E), false)) {
     case FDM_TILE_128x64_S3:                                                       // (retired id: the tile picks its ring depth)
     case FDM_TILE_128x64: {                                                        // 8 waves, 32x32 per wave
@@ -1250,7 +1251,7 @@ static hipError_t gemm_dispatch_split(const fdm_gemm_args& a, hipStream_t s) {
     return gemm_sched_fuse_launch<T>(a, s);
   const int tile_id = a.tile & FDM_TILE_ID_MASK;
   if (a.ksplit > 1) return gemm_dispatch_ksplit<T>(a, tile_id, s);
-  const int want = tile_id > 0 ? tile_id : gemm_tile_override();
+  const int want = tile_id > 0 ? tile_id : (a.batch2 >= 1 ? 0 : gemm_tile_override());
   switch (want > 0 ? want : gemm_heuristic_tile(a, 2, true)) {
     case FDM_TILE_64x64_S2: return gemm_glds_launch_t<T, 64, 64, 2, 4, 2, 4>(a, s);  // 64 KB -> 2 workgroups per CU
     case FDM_TILE_32x64_S3: return gemm_glds_launch_t<T, 32, 64, 2, 2, 3, 2>(a, s);  // 72 KB -> 2 workgroups per CU

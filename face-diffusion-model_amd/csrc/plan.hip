@@ -241,6 +241,7 @@ struct fdm_plan {
   // partial planes of x1, summed by that launch (fdm_gemm_args.ksplit / fdm_ln_args.x_planes).  A property of the plan, NOT of the
   // shape: results depend on S, and a clip must compute the same bits in every batch composition.
   int ksplit_out = 1, ksplit_ffn2 = 1;
+  int x1_planes = 0;                 // fp32 planes the workspace's x1 holds (one per K slice)
   int lockstep = 0;                          // fdm_plan_set "lockstep": the lockstep k loop in every GEMM of the step (A/B against the loader-wave form; same bits)
   int tune_lazy = 0;                         // 1: fdm_sample_graph may tune in-call once a shape has run 2000 steps (opt-in)
   long long last_graph_launches = 0, launches_per_step = 0;
@@ -273,8 +274,10 @@ Mat mat_rows(const fdm_plan* P, const Mat& m, size_t row0, size_t cols) {
 }
 
 std::string shape_key(const fdm_plan* P) {
-  char b[64];
-  snprintf(b, sizeof(b), "%d,%d,%d,%d,%d", P->R, P->M, P->L, P->rep, P->S);
+  // (the K-slice factors belong to the key: a tile set tuned without slices holds tiles a sliced launch cannot run on, and the other
+  //  way round -- in the in-process cache and in the FDM_TILE_CACHE file alike)
+  char b[80];
+  snprintf(b, sizeof(b), "%d,%d,%d,%d,%d,ks%d.%d", P->R, P->M, P->L, P->rep, P->S, P->ksplit_out, P->ksplit_ffn2);
   return b;
 }
 
@@ -513,7 +516,8 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   const fdm_model_desc& m = P->m;
   const size_t d = m.d, M = (size_t)B * L, R = M * repc;
   const size_t Lpad = ((size_t)L + 31) / 32 * 32;
-  FCK(dalloc_t(P, &P->h, R * d, true)); FCK(dalloc_t(P, &P->h2, R * d, true)); FCK(dalloc_t(P, &P->x1, R * d * 4, true));      // (x1: up to four split-K partial planes)
+  FCK(dalloc_t(P, &P->h, R * d, true)); FCK(dalloc_t(P, &P->h2, R * d, true)); P->x1_planes = std::max(1, std::max(P->ksplit_out, P->ksplit_ffn2));      // (x1: one fp32 plane per K slice of the plan's setting; plan_set grows it)
+  FCK(dalloc_t(P, &P->x1, R * d * P->x1_planes, true));
   FCK(dalloc_t(P, &P->x0, R * d, true)); FCK(dalloc_t(P, &P->x, M * d, true));
   if (P->dtype != FDM_F32) {
     FCK(dalloc_mat(P, &P->xt, M, d, true)); FCK(dalloc_mat(P, &P->ht, R, d, true)); FCK(dalloc_mat(P, &P->h2t, R, d, true));
@@ -1345,7 +1349,12 @@ int fdm_plan_set(fdm_plan* P, const char* key, long long value) {
     if (cur == (int)value) return FDM_OK;
     cur = (int)value;
     P->tile_cache.clear(); P->tiles.erase(k == "ksplit.out" ? "out" : "ffn2");
-    return drop_programs(P, nullptr);
+    FCK(drop_programs(P, nullptr));
+    if (P->capB > 0 && (int)value > P->x1_planes) {     // more partial planes than the workspace holds: a larger x1 (its contents do not outlive a step)
+      P->x1_planes = (int)value;
+      FCK(dalloc_t(P, &P->x1, (size_t)P->capB * P->capL * P->capRep * P->m.d * P->x1_planes, true));
+    }
+    return FDM_OK;
   }
   if (k == "lockstep") { P->lockstep = value != 0; P->tile_cache.clear(); P->tiles.clear(); return drop_programs(P, nullptr); }
   if (k == "untune") {      // forget the tuned tiles of every shape (tests)

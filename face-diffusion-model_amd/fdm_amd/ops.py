@@ -27,7 +27,7 @@ class Split:
     def __getitem__(self, sl):
         if not isinstance(sl, slice) or sl.stop is not None or sl.step is not None:
             raise _lib.FdmError("Split operands support [r0:] row offsets only")
-        return Split(self.planes, self.code, self.row0 + (sl.start or 0))
+        return Split(self.planes, self.code, self.row0 + (sl.start or 0), self.col0)
 
     @property
     def is_cuda(self):
@@ -46,7 +46,7 @@ class Split:
     def float(self):
         """hi + lo / SCALE as fp32 (tests)."""
         sc = 2048.0
-        return (self.planes[0].float() + self.planes[1].float() / sc)[self.row0:]
+        return (self.planes[0].float() + self.planes[1].float() / sc)[self.row0:, self.col0:]
 
 
 def cols(t, c0):
