@@ -31,7 +31,7 @@ namespace fdm {
 // accurate expf on the parity paths (fp32, split fp16), hardware exp2 on the bf16 (throughput) path
 // (bf16 callers pre-multiply the exponent by log2(e))
 template <typename T> __device__ __forceinline__ float fexp(float x) {
-  if constexpr (std::is_same<T, bf16>::value) return __builtin_amdgcn_exp2f(x);
+  if constexpr (is_fast16<T>::value) return __builtin_amdgcn_exp2f(x);
   else return expf(x);
 }
 
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
   }
 
   // bf16 path: softmax in the log2 domain (scale and slope carry log2(e); v_exp_f32 is a bare exp2)
-  constexpr float LG = std::is_same<T, bf16>::value ? 1.4426950408889634f : 1.f;
+  constexpr float LG = is_fast16<T>::value ? 1.4426950408889634f : 1.f;
   const float sc_mul = p.scale * LG;
   const float slope = p.slopes ? p.slopes[h] * LG : 0.f;
   const float inv_period = 1.f / (float)p.period;
@@ -240,8 +240,9 @@ __global__ __launch_bounds__(256, (attn_streamed<T, HD>() ? 1 : 2)) void attn_ke
       if constexpr (NP == 1) {
         u32x4 pf;
         if constexpr (sizeof(E) == 2) {
-          bf16x8 pb = {(bf16)sc[0][0], (bf16)sc[0][1], (bf16)sc[0][2], (bf16)sc[0][3],
-                       (bf16)sc[NSUB - 1][0], (bf16)sc[NSUB - 1][1], (bf16)sc[NSUB - 1][2], (bf16)sc[NSUB - 1][3]};
+          typedef __attribute__((ext_vector_type(8))) E e8p;
+          e8p pb = {(E)sc[0][0], (E)sc[0][1], (E)sc[0][2], (E)sc[0][3],
+                    (E)sc[NSUB - 1][0], (E)sc[NSUB - 1][1], (E)sc[NSUB - 1][2], (E)sc[NSUB - 1][3]};
           pf = __builtin_bit_cast(u32x4, pb);
         } else {
           pf = __builtin_bit_cast(u32x4, sc[0]);

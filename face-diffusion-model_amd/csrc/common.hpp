@@ -28,6 +28,11 @@ template <> struct Mma<bf16> {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
   }
 };
+template <> struct Mma<f16> {
+  static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  }
+};
 template <> struct Mma<float> {
   static __device__ __forceinline__ void run(f32x4& acc, const u32x4& a, const u32x4& b) {
     // (bit-cast the whole vector: __builtin_bit_cast(float, a[j]) on a vector element folds to element 0)
@@ -56,6 +61,9 @@ template <typename E> __device__ __forceinline__ void mma16(f32x4& acc, const u3
 // (f16x3 feeds the split attention kernel plane pairs).
 // ---------------------------------------------------------------------------------------------------
 struct f16x3_t {};
+// one-plane 16-bit kinds (bf16, and fp16 = the split kind's hi plane alone): the throughput modes -- hardware exp / log forms in
+// their activations and softmax, far inside the rounding of the 8- / 11-bit operand they feed
+template <typename T> struct is_fast16 { static constexpr bool value = std::is_same<T, bf16>::value || std::is_same<T, f16>::value; };
 template <typename T> struct Opnd { using E = T; using KV = T; static constexpr int NP = 1; static constexpr float SCALE = 1.f; };
 template <> struct Opnd<f16x3_t> { using E = f16; using KV = f16x3_t; static constexpr int NP = 2; static constexpr float SCALE = 2048.f; };
 
@@ -65,16 +73,27 @@ template <> struct Opnd<f16x3_t> { using E = f16; using KV = f16x3_t; static con
 // +1.4...2.7 %, single clips +0.6...2.7 %, cfg5 (1992 rows) -0.2...-0.7 %, HuBERT 0...+1.7 % (same box, alternating;
 // profiles/r5_store_policy/).  `sc0 sc1` measures the same; `nt` (with or without the scope bits) is 13 % slower.  Cache policy only:
 // the bytes stored are the same.
+// FDM_PLAIN_STORES (`make plainstores`): the same stores written in C++ -- the compiler's own instruction selection and hazard handling.
+// tests/test_store_policy_gpu.py runs the whole path on both builds and compares every output bit for bit: the hand-kept wait states
+// below are correct exactly as long as that test is green on the toolchain in use.
 __device__ __forceinline__ void st16(void* p, const f32x4& v) {
+#ifdef FDM_PLAIN_STORES
+  *(f32x4*)p = v;
+#else
   // (a VMEM store of more than 64 bits needs 2 wait states before a VALU write to its data registers on gfx940+; the compiler's
   //  hazard recogniser does not see into the asm, so the wait states travel with the store)
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
 }
 template <typename V8> __device__ __forceinline__ void st8(void* p, const V8& v) {
   static_assert(sizeof(V8) == 8, "st8 stores 8 bytes");
+#ifdef FDM_PLAIN_STORES
+  *(V8*)p = v;
+#else
   typedef __attribute__((ext_vector_type(2))) int i2;
   const i2 w = __builtin_bit_cast(i2, v);
   asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
+#endif
 }
 // Store 4 consecutive fp32 values v as operand kind T at dst (split kinds: hi plane at dst, lo plane at dst + lo_off).
 template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, long long lo_off, const f32x4& v) {
@@ -83,7 +102,9 @@ template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, lon
     st16(dst, v);
   } else if constexpr (Opnd<T>::NP == 1) {
     typedef __attribute__((ext_vector_type(4))) E e4;
-    e4 o = {(E)v[0], (E)v[1], (E)v[2], (E)v[3]};
+    e4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (E)(std::is_same<E, f16>::value ? fminf(fmaxf(v[j], -65504.f), 65504.f) : v[j]);      // (fp16 overflows at 65504)
     st8(dst, o);
   } else {
     typedef __attribute__((ext_vector_type(4))) E e4;
@@ -102,7 +123,7 @@ template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, lon
 template <typename T> __device__ __forceinline__ void store_opnd1(void* dst, long long lo_off, float v) {
   using E = typename Opnd<T>::E;
   if constexpr (Opnd<T>::NP == 1) {
-    *(E*)dst = (E)v;
+    *(E*)dst = (E)(std::is_same<E, f16>::value ? fminf(fmaxf(v, -65504.f), 65504.f) : v);
   } else {
     const float x = std::is_same<E, f16>::value ? fminf(fmaxf(v, -65504.f), 65504.f) : v;
     const E h = (E)x;
@@ -116,6 +137,8 @@ __device__ __forceinline__ float to_f32(bf16 v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16 from_f32<bf16>(float v) { return (bf16)v; }
+template <> __device__ __forceinline__ f16 from_f32<f16>(float v) { return (f16)v; }
+__device__ __forceinline__ float to_f32(f16 v) { return (float)v; }
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   switch (act) {
@@ -147,7 +170,7 @@ __device__ __forceinline__ float gelu_erf_fast(float v) {
 }
 // activation in the arithmetic of operand kind T: the bf16 kind takes the fast GELU above, every other kind act_apply
 template <typename T> __device__ __forceinline__ float act_apply_t(float v, int act) {
-  if constexpr (std::is_same<T, bf16>::value) { if (act == ACT_GELU_ERF) return gelu_erf_fast(v); }
+  if constexpr (is_fast16<T>::value) { if (act == ACT_GELU_ERF) return gelu_erf_fast(v); }
   return act_apply(v, act);
 }
 

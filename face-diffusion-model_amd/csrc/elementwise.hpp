@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void sched_kernel(const fdm_sched_args p) {
     if (p.x_out_t) {
       if (p.out_dtype == FDM_BF16) store_opnd4<bf16>((bf16*)p.x_out_t + 4 * i, 0, o);
       else if (p.out_dtype == FDM_F16X3) store_opnd4<f16x3_t>((f16*)p.x_out_t + 4 * i, p.x_out_t_lo_off, o);
+      else if (p.out_dtype == FDM_F16) store_opnd4<f16>((f16*)p.x_out_t + 4 * i, 0, o);
       else *(f32x4*)((float*)p.x_out_t + 4 * i) = o;
     }
   }

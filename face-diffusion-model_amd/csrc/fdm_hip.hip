@@ -104,7 +104,7 @@ static bool gemm_act_heavy_host(int act) { return act == FDM_ACT_MISH || act == 
 int fdm_op_gemm(const fdm_gemm_args* a, void* stream) {
   if (!a || !a->A || !a->W) return fail(FDM_ERR_ARG, "gemm: null operand");
   if (a->M <= 0 || a->N <= 0 || a->K <= 0) return fail(FDM_ERR_SHAPE, "gemm: M,N,K must be positive (%d,%d,%d)", a->M, a->N, a->K);
-  if (a->dtype < FDM_F32 || a->dtype > FDM_F16X3) return fail(FDM_ERR_ARG, "gemm: bad dtype %d", a->dtype);
+  if (a->dtype < FDM_F32 || a->dtype > FDM_F16) return fail(FDM_ERR_ARG, "gemm: bad dtype %d", a->dtype);
   const bool split = a->dtype == FDM_F16X3;
   const int bk = a->dtype == FDM_F32 ? 32 : 64, epc = a->dtype == FDM_F32 ? 4 : 8;
   if (split && (a->a_lo_off <= 0 || a->w_lo_off <= 0 || a->a_lo_off % epc || a->w_lo_off % epc))
@@ -179,7 +179,7 @@ int fdm_op_attention(const fdm_attn_args* a, void* stream) {
   if (a->hd != 64 && a->hd != 128 && a->hd != 256) return fail(FDM_ERR_SHAPE, "attention: head_dim %d unsupported (64, 128, 256)", a->hd);
   if (a->B <= 0 || a->H <= 0 || a->L <= 0) return fail(FDM_ERR_SHAPE, "attention: B,H,L must be positive");
   if (a->Lpad < a->L || a->Lpad % 32) return fail(FDM_ERR_SHAPE, "attention: Lpad=%d must be a multiple of 32 >= L", a->Lpad);
-  if (a->dtype != FDM_F32 && a->dtype != FDM_BF16 && a->dtype != FDM_F16X3) return fail(FDM_ERR_ARG, "attention: bad dtype %d (FDM_F32, FDM_BF16, FDM_F16X3)", a->dtype);
+  if (a->dtype < FDM_F32 || a->dtype > FDM_F16) return fail(FDM_ERR_ARG, "attention: bad dtype %d (FDM_F32, FDM_BF16, FDM_F16X3, FDM_F16)", a->dtype);
   if (a->o_split && (a->dtype != FDM_F32 || a->o_split != FDM_F16X3 || a->o_lo_off <= 0))
     return fail(FDM_ERR_ARG, "attention: o_split needs dtype FDM_F32, a split kind and o_lo_off");
   if (a->dtype == FDM_F16X3 && (a->q_lo_off <= 0 || a->kv_lo_off <= 0 || a->o_lo_off <= 0 || a->q_lo_off % 8 || a->kv_lo_off % 8 || a->o_lo_off % 4))
@@ -210,8 +210,8 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
   if (a->d != 256 && a->d != 512 && a->d != 768 && a->d != 1024) return fail(FDM_ERR_SHAPE, "layernorm: d=%d unsupported (256, 512, 768, 1024)", a->d);
   if (a->M <= 0) return fail(FDM_ERR_SHAPE, "layernorm: M must be positive");
   if (!a->y_f32 && !a->y_t) return fail(FDM_ERR_ARG, "layernorm: no output");
-  if (a->dtype < FDM_F32 || a->dtype > FDM_F16X3) return fail(FDM_ERR_ARG, "layernorm: bad dtype %d", a->dtype);
-  if (a->y_t && a->dtype >= FDM_F16X3 && (a->y_t_lo_off <= 0 || a->y_t_lo_off % 4)) return fail(FDM_ERR_ARG, "layernorm: split y_t needs y_t_lo_off");
+  if (a->dtype < FDM_F32 || a->dtype > FDM_F16) return fail(FDM_ERR_ARG, "layernorm: bad dtype %d", a->dtype);
+  if (a->y_t && a->dtype == FDM_F16X3 && (a->y_t_lo_off <= 0 || a->y_t_lo_off % 4)) return fail(FDM_ERR_ARG, "layernorm: split y_t needs y_t_lo_off");
   if (a->add_mat_group < 0 || a->add_mat_wrap < 0 ||
       (a->add_mat_group > 0 && (a->add_mat_L <= 0 || a->add_mat_group % a->add_mat_L || (a->add_mat_wrap > 0 && a->add_mat_wrap % a->add_mat_group))))
     return fail(FDM_ERR_SHAPE, "layernorm: shared add_mat needs add_mat_L | add_mat_group | add_mat_wrap (got %d, %d, %d)", a->add_mat_L, a->add_mat_group, a->add_mat_wrap);
@@ -222,6 +222,7 @@ int fdm_op_layernorm(const fdm_ln_args* a, void* stream) {
     switch (c.dtype) {
       case FDM_BF16: return fdm::ln_launch_t<fdm::bf16>(c, s);
       case FDM_F16X3: return fdm::ln_launch_t<fdm::f16x3_t>(c, s);
+      case FDM_F16: return fdm::ln_launch_t<fdm::f16>(c, s);
       default: return fdm::ln_launch_t<float>(c, s);
     }
   }, stream, "layernorm");
@@ -234,18 +235,20 @@ int fdm_op_sched_step(const fdm_sched_args* a, void* stream) {
   if (a->mode == 1 && (!a->x || !a->sra || !a->srm1 || !a->sqrt_an || !a->c_n)) return fail(FDM_ERR_ARG, "sched: DDIM tables missing");
   if (a->mode < 0 || a->mode > 2) return fail(FDM_ERR_ARG, "sched: bad mode %d", a->mode);
   if (a->mode == 0 && !a->noise && (a->n_per_clip <= 0 || a->n_per_clip % 4)) return fail(FDM_ERR_SHAPE, "sched: n_per_clip must be a positive multiple of 4");
-  if (a->x_out_t && a->out_dtype >= FDM_F16X3 && (a->x_out_t_lo_off <= 0 || a->x_out_t_lo_off % 4)) return fail(FDM_ERR_ARG, "sched: split x_out_t needs x_out_t_lo_off");
+  if (a->x_out_t && (a->out_dtype < FDM_F32 || a->out_dtype > FDM_F16)) return fail(FDM_ERR_ARG, "sched: bad out_dtype %d", a->out_dtype);
+  if (a->x_out_t && a->out_dtype == FDM_F16X3 && (a->x_out_t_lo_off <= 0 || a->x_out_t_lo_off % 4)) return fail(FDM_ERR_ARG, "sched: split x_out_t needs x_out_t_lo_off");
   fdm_sched_args c = *a;
   return submit([c](hipStream_t s) { return fdm::sched_launch(c, s); }, stream, "sched");
 }
 
 int fdm_op_cast(const float* src, void* dst, long long n, int dtype, void* stream) {
   if (!src || !dst || n <= 0) return fail(FDM_ERR_ARG, "cast: bad argument");
-  if (dtype < FDM_F32 || dtype > FDM_F16X3) return fail(FDM_ERR_ARG, "cast: bad dtype %d", dtype);
+  if (dtype < FDM_F32 || dtype > FDM_F16) return fail(FDM_ERR_ARG, "cast: bad dtype %d", dtype);
   return submit([=](hipStream_t s) {
     const dim3 g(grid_for(n)), b(256);
     if (dtype == FDM_BF16) hipLaunchKernelGGL((fdm::cast_kernel<fdm::bf16>), g, b, 0, s, src, (fdm::bf16*)dst, n);
     else if (dtype == FDM_F16X3) hipLaunchKernelGGL((fdm::cast_kernel<fdm::f16x3_t>), g, b, 0, s, src, (fdm::f16*)dst, n);
+    else if (dtype == FDM_F16) hipLaunchKernelGGL((fdm::cast_kernel<fdm::f16>), g, b, 0, s, src, (fdm::f16*)dst, n);
     else hipLaunchKernelGGL((fdm::cast_kernel<float>), g, b, 0, s, src, (float*)dst, n);
     return hipGetLastError();
   }, stream, "cast");

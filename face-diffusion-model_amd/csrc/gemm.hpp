@@ -109,8 +109,8 @@ __device__ __forceinline__ void gemm_epi_preload(const fdm_gemm_args& p, int m0,
 template <bool HEAVY, typename T> __device__ __forceinline__ float gemm_act(float v, int act) {
   if constexpr (!HEAVY) {
     return act == ACT_RELU ? fmaxf(v, 0.f) : (act == ACT_LEAKY02 ? (v > 0.f ? v : 0.2f * v) : v);
-  } else if constexpr (std::is_same<T, bf16>::value) {
-    // bf16 (throughput) mode: hardware exp / log forms, ~1e-6 relative -- far inside the bf16 operand rounding
+  } else if constexpr (is_fast16<T>::value) {
+    // bf16 / fp16 (throughput) modes: hardware exp / log forms, ~1e-6 relative -- far inside the bf16 operand rounding
     if (act == ACT_MISH) {
       const float sp = v > 20.f ? v : __logf(1.f + __expf(v));
       return v * (1.f - 2.f / (1.f + __expf(2.f * sp)));

@@ -524,13 +524,13 @@ int reserve(fdm_plan* P, int B, int L, int cfg) {
   } else {        // fp32 operands alias the fp32 residual-stream buffers
     P->xt = Mat{P->x, 0}; P->ht = Mat{P->h, 0}; P->h2t = Mat{P->h2, 0};
   }
-  if (P->dtype == FDM_BF16 || P->dtype == FDM_F16X3) {     // folded-norm3 buffers (raw rows, their operand copy, per-row partial sums)
+  if (P->dtype != FDM_F32) {     // folded-norm3 buffers (raw rows, their operand copy, per-row partial sums)
     FCK(dalloc_t(P, &P->x2, R * d, true)); FCK(dalloc_mat(P, &P->x2t, R, d, true)); FCK(dalloc_t(P, &P->stats, (d / 64) * R * 2, true));
   }
   // q: row-major queries; kp / vp: fragment-packed keys / values written by the QKV GEMM's epilogue (zeroed: pad keys must be
   // finite).  Split modes: attention runs in fp32, ctx returns as a plane pair.
   // (FDM_F16X3: fp16 plane pairs, the same bytes as fp32)
-  const size_t ea = P->dtype == FDM_BF16 ? 2 : 4;
+  const size_t ea = (P->dtype == FDM_BF16 || P->dtype == FDM_F16) ? 2 : 4;
   FCK(dalloc(P, &P->q, R * d * ea, true));
   FCK(dalloc(P, &P->kp, (size_t)B * repc * Lpad * d * ea, true));
   FCK(dalloc(P, &P->vp, (size_t)B * repc * Lpad * d * ea, true));
@@ -1070,7 +1070,7 @@ extern "C" {
 
 int fdm_plan_create(const fdm_model_desc* desc, int B, int L, int cfg, int dtype, fdm_plan** out) {
   if (!desc || !out) return fail(FDM_ERR_ARG, "plan_create: null argument");
-  if (dtype < FDM_F32 || dtype > FDM_F16X3) return fail(FDM_ERR_ARG, "plan_create: bad dtype %d", dtype);
+  if (dtype < FDM_F32 || dtype > FDM_F16) return fail(FDM_ERR_ARG, "plan_create: bad dtype %d", dtype);
   const fdm_model_desc& m = *desc;
   if (m.d <= 0 || m.n_head <= 0 || m.d % m.n_head || m.n_layers <= 0 || m.ffn <= 0 || m.G * m.c != m.d || m.pair <= 0 || m.max_len <= 0)
     return fail(FDM_ERR_SHAPE, "plan_create: inconsistent model geometry (d %d, heads %d, G*c %d)", m.d, m.n_head, m.G * m.c);

@@ -7,8 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # FDM_LIB_PATH: load another build of the same library (the AddressSanitizer host build, csrc `make asan`)
 LIB_PATH = os.environ.get("FDM_LIB_PATH") or os.path.join(_HERE, "libfdm_hip.so")
 
-F32, BF16, F16X3 = 0, 1, 2      # include/fdm_hip.h FDM_*: operand kinds (the last one is a split plane pair)
-DTYPE_NAMES = {"f32": F32, "bf16": BF16, "f16x3": F16X3}
+F32, BF16, F16X3, F16 = 0, 1, 2, 3      # include/fdm_hip.h FDM_*: operand kinds (F16X3 is a split plane pair; F16 its hi plane alone: denoiser only)
+DTYPE_NAMES = {"f32": F32, "bf16": BF16, "f16x3": F16X3, "f16": F16}
 ACT_NONE, ACT_RELU, ACT_MISH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02 = range(6)
 
 vp, ll, ci, cf = C.c_void_p, C.c_longlong, C.c_int, C.c_float

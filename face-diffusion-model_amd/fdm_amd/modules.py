@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from . import ops, presets, schedule, synth
-from ._lib import BF16, DTYPE_NAMES, F16X3, F32, FdmError
+from ._lib import BF16, DTYPE_NAMES, F16, F16X3, F32, FdmError
 from .denoiser import DenoiserPlan
 from .hubert import HUBERT_LARGE, WAV2VEC2_BASE, HubertPlan, num_frames
 from .vq import VQPlan
@@ -32,7 +32,8 @@ from .vq import VQPlan
 
 def compute_dtype(name=None):
     """Arithmetic mode of the HIP path: "fp32" (default; exact fp32 MFMA), "f16x3" (split-fp16 operands on the 16-bit matrix
-    cores: same 1e-4 contract, ~1.6x the frames/s), "bf16" (throughput mode, BASELINE.json configs[1])."""
+    cores: same 1e-4 contract, ~1.6x the frames/s), "bf16" (throughput mode, BASELINE.json configs[1]), "f16" (single-plane fp16: bf16's
+    speed, 11 significand bits instead of 8 in the step program; encoder on split-fp16 operands, VQ stages in fp32)."""
     name = (name or os.environ.get("FDM_AMD_DTYPE", "fp32")).lower()
     name = {"fp32": "f32", "float32": "f32", "bfloat16": "bf16"}.get(name, name)
     if name not in DTYPE_NAMES:
@@ -50,6 +51,8 @@ def _side_dtype(dt):
 def _audio_dtype(dt):
     """The audio encoders follow the step program's mode where they have it: fp32, bf16, or f16x3 (split-fp16 transformer layers
     and conv front: inside the 1e-4 contract at about half the fp32 encoder's time)."""
+    if dt == F16:      # single-plane fp16 is a mode of the step program only: the once-per-clip encoder runs on split-fp16 operands
+        return F16X3
     return dt if dt in (F32, BF16, F16X3) else F32
 
 

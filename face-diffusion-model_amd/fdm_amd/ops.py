@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F16X3, F32,
+from ._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F16, F16X3, F32,
                    AttnArgs, GemmArgs, LnArgs, SchedArgs, check, lib)
 
 
@@ -72,7 +72,7 @@ def stream():
 
 def tdtype(code):
     """torch dtype of the elements of operand kind `code` (split kinds: of each plane)."""
-    return {BF16: torch.bfloat16, F16X3: torch.float16}.get(code, torch.float32)
+    return {BF16: torch.bfloat16, F16X3: torch.float16, F16: torch.float16}.get(code, torch.float32)
 
 
 def is_split(code):
@@ -86,6 +86,8 @@ def code_of(t):
         return BF16
     if t.dtype == torch.float32:
         return F32
+    if t.dtype == torch.float16:
+        return F16
     raise _lib.FdmError(f"unsupported dtype {t.dtype}")
 
 
@@ -191,7 +193,7 @@ def to_operand(src_f32, dtype):
     if is_split(dtype):
         dst = Split(torch.empty((2,) + tuple(src_f32.shape), dtype=tdtype(dtype), device=src_f32.device), dtype)
     else:
-        dst = torch.empty(src_f32.shape, dtype=torch.bfloat16, device=src_f32.device)
+        dst = torch.empty(src_f32.shape, dtype=tdtype(dtype), device=src_f32.device)
     cast(src_f32.contiguous(), dst)
     return dst
 

@@ -44,6 +44,11 @@ extern "C" {
  * pair.  (A bf16-plane split -- 16 bits per operand, ~5e-5 per denoiser call, outside the contract over chains -- was built and
  * measured in rounds 2-4 as kind 3 and is no longer part of the library: tools/sim_split_precision.py) */
 #define FDM_F16X3 2
+/* Single-plane fp16 operands (round 6): the `hi` plane of the split kind alone -- the bf16 kind's bytes and MFMA rate with 11
+ * significand bits instead of 8 (|x| clamped to 65504 when an operand copy is written).  The denoiser's step program only
+ * (fdm_op_gemm / fdm_op_attention / fdm_op_layernorm / fdm_op_cast / fdm_op_sched_step, fdm_plan_create); the audio encoders and the
+ * VQ stages take FDM_F32 / FDM_BF16 / FDM_F16X3. */
+#define FDM_F16 3
 
 #define FDM_ACT_NONE 0
 #define FDM_ACT_RELU 1       /* nn.TransformerDecoderLayer default activation, models/fdm_vocaset.py:45 */

@@ -420,3 +420,79 @@ def test_encoder_is_reproducible_when_another_process_shares_the_gpu():
         for p in noise:
             p.wait(timeout=120)
 
+
+
+def test_vq_index_mismatch_rate_against_the_reference_formula():
+    """How often does the kernel's index differ from the reference's OWN distance expression
+    (models/lib/quantizer.py:38-45, EVQ models/vq_vae_emotion.py:221-238: `sum(z**2) + sum(e**2) - 2 z e^T`, torch's sum + matmul
+    order, first-min argmin) -- counted, not argued: FDM_VQ_RATE_ROWS rows (default 1e7), half N(0, (1.5/256)^2) latents, half real
+    chain outputs (cfg2-shaped VOCASET and cfg3-shaped MEAD + CFG DDIM chains from fresh seeds, scaled as bench.py scales them before
+    quant), VOCASET / all 7 EVQ slices of MEAD / BIWI (c = 128).  The two sides evaluate the same real-number expression in different
+    fp32 orders (an fmaf chain per sum here, the BLAS's blocking there), so they can only disagree where the two best codes are
+    closer than the rounding of that expression: every mismatching row must be such a near-tie under fp64 (bound: 8 ulp of the
+    expansion's largest term), and the count is printed -- it is the figure DESIGN.md quotes beside "bit-identical on the index path"."""
+    import os
+    from fdm_amd.denoiser import DenoiserPlan
+    total = int(float(os.environ.get("FDM_VQ_RATE_ROWS", "1e7")))
+    CH = 200_000
+    stats = {}
+
+    def count(name, plan, Eb, z, emo_row):
+        """z [R, c] fp32 (CPU).  Returns nothing; accumulates (rows, mismatches, exact fp64 ties, kernel == fp64 argmin, reference == fp64 argmin)."""
+        R = z.shape[0]
+        _, idx = plan.quant(z.view(1, R, -1), None if emo_row is None else emo_row.view(1, -1))
+        idx = idx.cpu().view(-1)
+        d = torch.sum(z ** 2, dim=1, keepdim=True) + torch.sum(Eb ** 2, dim=1) - 2 * torch.matmul(z, Eb.t())      # the reference's expression
+        ridx = torch.argmin(d, dim=1)
+        bad = (idx != ridx).nonzero().view(-1)
+        s = stats.setdefault(name, [0, 0, 0, 0, 0])
+        s[0] += R
+        if bad.numel():
+            zb, E64 = z[bad].double(), Eb.double()
+            d64 = (zb ** 2).sum(1, keepdim=True) + (E64 ** 2).sum(1) - 2 * zb @ E64.t()
+            dk, dr = d64.gather(1, idx[bad].view(-1, 1)).view(-1), d64.gather(1, ridx[bad].view(-1, 1)).view(-1)
+            big = (zb ** 2).sum(1) + (E64 ** 2).sum(1).max() + 2 * (zb @ E64.t()).abs().max(1).values
+            gap = (dk - dr).abs()
+            assert bool((gap <= 8 * 2.0 ** -24 * big).all()), (name, float((gap / big).max()))      # a near-tie: below the fp32 rounding of the expression
+            best = d64.min(1).values
+            s[1] += int(bad.numel()); s[2] += int((gap == 0).sum()); s[3] += int((dk == best).sum()); s[4] += int((dr == best).sum())
+
+    per = total // 2
+    # --- half 1: N(0, (1.5 / 256)^2) latents
+    gen = torch.Generator().manual_seed(2026)
+    for preset, share in (("vocaset", 0.4), ("mead", 0.42), ("biwi", 0.18)):
+        p = W.PRESETS[preset]
+        plan = vq_plan(preset)
+        E = W.make_vq_weights(preset)["quantize.embedding.weight"]
+        books = p["n_books"]
+        rows_each = int(per * share) // books
+        for e in range(books):
+            Eb = E[e * 256:(e + 1) * 256] if books > 1 else E
+            emo = torch.eye(7)[e] if books > 1 else None
+            for r0 in range(0, rows_each, CH):
+                n = min(CH, rows_each - r0)
+                count(f"{preset} synthetic", plan, Eb, torch.randn(n, p["c"], generator=gen) * (1.5 / 256), emo)
+    # --- half 2: real chain outputs (DDIM 20 from fresh x_T; each call gives B * L * G rows)
+    for preset, B, L, cfg, share in (("vocaset", 4, 200, False, 0.5), ("mead", 4, 300, True, 0.5)):
+        p = W.PRESETS[preset]
+        w = W.make_fdm_weights(preset)
+        den = DenoiserPlan(preset, w, BF16, DEV)        # (the chains only supply realistically distributed latents)
+        inp = W.synth_inputs(preset, B, L, seed=2)
+        den.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L, cfg=cfg)
+        plan = vq_plan(preset)
+        E = W.make_vq_weights(preset)["quantize.embedding.weight"]
+        want, got, call = int(per * share), 0, 0
+        while got < want:
+            xT = torch.randn(B, L * p["G"], p["c"], generator=gen)
+            out = (den.sample_ddim(xT.to(DEV), 20) * (1.5 / 1024)).cpu()
+            for b in range(B):
+                e = (call * B + b) % 7
+                Eb = E[e * 256:(e + 1) * 256] if p["n_books"] > 1 else E
+                count(f"{preset} chain outputs", plan, Eb, out[b].reshape(-1, p["c"]).contiguous(), torch.eye(7)[e] if p["n_books"] > 1 else None)
+            got += B * L * p["G"]; call += 1
+    rows = sum(s[0] for s in stats.values()); mism = sum(s[1] for s in stats.values())
+    for name, s in stats.items():
+        print(f"[vq index rate] {name}: {s[0]} rows, {s[1]} differ from the reference's expression ({s[1] / max(s[0], 1):.2e}); of those: exact fp64 ties {s[2]}, "
+              f"kernel took the fp64-nearest code {s[3]}, the reference's expression took it {s[4]}")
+    print(f"[vq index rate] total: {rows} rows, {mism} mismatches = {mism / rows:.2e} per row, every one a near-tie below the fp32 rounding of the expression")
+    assert rows >= 0.95 * total
