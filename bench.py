@@ -12,6 +12,7 @@ collective is the all-gather of the finished latents, inside the timed region.
 
 Default invocation (the line the driver records) carries three more things besides the headline leg (--dtype, default bf16 =
 BASELINE.json configs[1]):
+  "f16_mode"       the same workload on single-plane fp16 operands (round 6): bf16's speed, ~8x closer to the reference
   "contract_mode"  the same workload timed in f16x3 -- the mode that meets north_star's 1e-4 tolerance on the 16-bit matrix
                    cores -- with its own HIP-event roofline and its own parity figure;
   "parity"         max-abs of the headline mode's plan against tests/golden/chains_vocaset.npz (outputs of the reference itself:
@@ -473,6 +474,11 @@ def main():
         del plan
         contract, _, _ = run_leg("f16x3", a.contract_steps, a.warmup, True)
         contract["roofline"]["kernel"] = "denoiser step graph in the contract mode (split-fp16 operands, three 16-bit MFMA passes per product)"
+    f16leg = None
+    if not a.headline_only and not a.profile_steps and a.dtype == "bf16" and world == 1:
+        # the throughput mode's closer twin (round 6): single-plane fp16 operands -- bf16's bytes and MFMA rate, 11 significand bits --
+        # timed and checked against the same reference chains, so the line shows what the headline's 8 bits cost beside what they buy
+        f16leg, _, _ = run_leg("f16", a.contract_steps, a.warmup, True)
 
     if rank == 0:
         # Counter-derived fields (HBM-side bytes per launch of the step graph, MFMA-busy share, the dominant kernel's own
@@ -568,6 +574,11 @@ def main():
                                     "gemm_tiles": contract["gemm_tiles"],
                                     "parity_max_abs": contract.get("parity_max_abs"), "tolerance": 1e-4,
                                     "what": "the same workload in the arithmetic mode that meets north_star's 1e-4 max-abs tolerance"}
+        if f16leg is not None:
+            res["f16_mode"] = {"dtype": "f16", "value": f16leg["value"], "unit": "frames/s", "steps": f16leg["steps"], "ms_per_step": f16leg["ms_per_step"],
+                               "roofline_frac": f16leg["roofline"]["frac"], "gemm_tiles": f16leg["gemm_tiles"],
+                               "parity_max_abs": f16leg.get("parity_max_abs"), "tolerance": PARITY_TOL["f16"], "within_1e-4_contract": False,
+                               "what": "the same workload on single-plane fp16 operands (FDM_F16: the split kind's hi plane alone)"}
         if not a.no_cpu_baseline and world == 1:
             # the bounded CPU sample is defined for the denoiser-only configs; cfg4/cfg5 reuse cfg2's shape class
             res["cpu_baseline"] = cpu_baseline(a.config if a.config in ("cfg1", "cfg2", "cfg3") else ("cfg1" if (a.config == "cfg1x8" or shipped) else "cfg2"))

@@ -415,6 +415,12 @@ __device__ __forceinline__ void gemm_epilogue(const fdm_gemm_args& p, f32x4 (&ac
 // The step's GEMMs have M = B*L of a few hundred rows: a block owns one tile for the whole K loop, so
 // what bounds it is the latency chain of its own k-tiles, not bandwidth -- hence the deep ring.
 // ---------------------------------------------------------------------------------------------------
+// FDM_LW_VARIANT (tools/lw_probe.cpp only; 0 in every build of the library): the k loop of gemm_glds_kernel with parts removed -- bit 0 no
+// MFMAs, bit 1 no fragment reads, bit 2 no LDS-DMA after the prologue's NST - 1 tiles.  Results of the reduced variants are meaningless;
+// only their durations are read (round 6: which phase bounds the loader-wave loop at 1992-3984 rows).
+#ifndef FDM_LW_VARIANT
+#define FDM_LW_VARIANT 0
+#endif
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const vo
           wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();           // tile kt landed (every loader's share); the compute waves are done with stage (kt-1) % NST
-        if (kt + NST - 1 < nk) issue(kt + NST - 1);
+        if constexpr (!(FDM_LW_VARIANT & 4)) { if (kt + NST - 1 < nk) issue(kt + NST - 1); }
       }
       return;                                   // (a finished wave leaves the workgroup's barrier count: the epilogue's barriers are the compute waves')
     }
@@ -636,9 +642,9 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const vo
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) af[s][mi][pl] = frag_a(base, pl, s, mi);
+          for (int mi = 0; mi < MI; ++mi) af[s][mi][pl] = (FDM_LW_VARIANT & 2) ? u32x4{(unsigned)kt, 1u, 2u, 3u} : frag_a(base, pl, s, mi);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) wf[s][ni][pl] = frag_w(base, pl, s, ni);
+          for (int ni = 0; ni < NI; ++ni) wf[s][ni][pl] = (FDM_LW_VARIANT & 2) ? u32x4{(unsigned)kt, 5u, 6u, 7u} : frag_w(base, pl, s, ni);
         }
       if (LW == 0 && kt + NST - 1 < nk) issue(kt + NST - 1);
 #pragma unroll
@@ -646,7 +652,10 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const vo
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) mma(mi, ni, wf[s][ni], af[s][mi]);
+          for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (FDM_LW_VARIANT & 1) { asm volatile("" ::"v"(wf[s][ni][0]), "v"(af[s][mi][0])); }      // (keeps the fragment reads alive)
+            else mma(mi, ni, wf[s][ni], af[s][mi]);
+          }
     } else {
       if (LW == 0 && kt + NST - 1 < nk) issue(kt + NST - 1);
 #pragma unroll
@@ -655,14 +664,17 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const vo
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) {
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi) af[mi][pl] = frag_a(base, pl, s, mi);
+          for (int mi = 0; mi < MI; ++mi) af[mi][pl] = (FDM_LW_VARIANT & 2) ? u32x4{(unsigned)kt, 1u, 2u, 3u} : frag_a(base, pl, s, mi);
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) wf[ni][pl] = frag_w(base, pl, s, ni);
+          for (int ni = 0; ni < NI; ++ni) wf[ni][pl] = (FDM_LW_VARIANT & 2) ? u32x4{(unsigned)kt, 5u, 6u, 7u} : frag_w(base, pl, s, ni);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NI; ++ni) mma(mi, ni, wf[ni], af[mi]);
+          for (int ni = 0; ni < NI; ++ni) {
+            if constexpr (FDM_LW_VARIANT & 1) { asm volatile("" ::"v"(wf[ni][0]), "v"(af[mi][0])); }
+            else mma(mi, ni, wf[ni], af[mi]);
+          }
       }
     }
   }
@@ -1229,6 +1241,10 @@ static hipError_t gemm_dispatch(const fdm_gemm_args& a, hipStream_t s) {
     case FDM_TILE_128x64: {                                                        // 8 waves, 32x32 per wave
       // 4-stage ring (96 KB, one per CU) while the grid is one round; beyond that the 3-stage ring (72 KB): two workgroups per CU
       const long long wgs = (long long)((a.M + 127) / 128) * ((a.N + 63) / 64) * (a.batch > 0 ? a.batch : 1) * (a.batch2 > 0 ? a.batch2 : 1);
+      // (Round 6, measured and not adopted: four compute waves of 64x32 instead of eight of 32x32 beyond one round -- fewer fragment bytes read
+      //  from LDS per staged byte -- is 7-11 % faster on the isolated QKV / FFN1 shapes at 1992 rows with a plain epilogue and 1-1.7 % SLOWER
+      //  inside cfg5's step program and HuBERT-large, where the epilogue's residual / packed-K,V operands share the registers:
+      //  profiles/r6_loop_ablation/.)
       return wgs <= 256 ? gemm_glds_launch_t<T, 128, 64, 4, 2, 4, 4>(a, s) : gemm_glds_launch_t<T, 128, 64, 4, 2, 3, 4>(a, s);
     }
     case FDM_TILE_96x128:                                                          // (retired id: nearest member)

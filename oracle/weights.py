@@ -191,9 +191,22 @@ def _is_norm(name):
     return ("norm" in name) and ("to_" not in name)
 
 
+_MADE = {}      # (shapes, seed, prefix) -> tensors: the suites ask for the same few weight sets dozens of times (HuBERT-large is 315 M values)
+
+
 def make_weights(shapes, seed=0, prefix=""):
     """name -> fp32 tensor.  Matrices ~ N(0, 1/fan_in) so activations stay O(1); biases N(0, 0.02);
-    LayerNorm weights 1 + N(0, 0.1); codebooks U(-1/K, 1/K) as in models/lib/quantizer.py:33."""
+    LayerNorm weights 1 + N(0, 0.1); codebooks U(-1/K, 1/K) as in models/lib/quantizer.py:33.
+    (Memoised per process: callers get a fresh dict over shared, read-only tensors.)"""
+    key = (tuple((k, tuple(v)) for k, v in shapes.items()), seed, prefix)
+    if key in _MADE:
+        return dict(_MADE[key])
+    out = _make_weights(shapes, seed, prefix)
+    _MADE[key] = out
+    return dict(out)
+
+
+def _make_weights(shapes, seed, prefix):
     out = {}
     for name, shape in shapes.items():
         g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ (seed * 0x9E3779B1)) & 0x7FFFFFFF)

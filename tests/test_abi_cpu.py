@@ -213,6 +213,12 @@ def test_plan_layer_argument_validation_without_device():
     # this box the call gets as far as "no device"; an unsupported head_dim is a shape error
     rc = l.fdm_plan_create(C.byref(pd), 1, 10, 0, _lib.F16X3, C.byref(p))
     assert (rc == -4 and b"no gfx950 device" in l.fdm_last_error()) or (rc == 0 and l.fdm_plan_destroy(p) == 0)
+    # FDM_F16 (round 6: single-plane fp16) is a kind of the step program only: the plan takes it, the audio encoders (above) and the VQ stages do not
+    rc = l.fdm_plan_create(C.byref(pd), 1, 10, 0, _lib.F16, C.byref(p))
+    assert (rc == -4 and b"no gfx950 device" in l.fdm_last_error()) or (rc == 0 and l.fdm_plan_destroy(p) == 0)
+    assert l.fdm_plan_create(C.byref(pd), 1, 10, 0, 4, C.byref(p)) == -1 and b"dtype" in l.fdm_last_error()
+    dq = _lib.VqDesc(16, 64, 256, 1, 15069, 0)
+    assert l.fdm_vq_create(C.byref(dq), _lib.F16, C.byref(v)) == -1
     pd.n_head = 32
     assert l.fdm_plan_create(C.byref(pd), 1, 10, 0, _lib.F16X3, C.byref(p)) == -2 and b"head_dim" in l.fdm_last_error()
 

@@ -14,7 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from fdm_amd._lib import BF16, F16X3, F32  # noqa: E402
+from fdm_amd._lib import BF16, F16, F16X3, F32  # noqa: E402
 from fdm_amd.denoiser import DenoiserPlan  # noqa: E402
 from oracle import fdm_oracle as FO  # noqa: E402
 from oracle import weights as W  # noqa: E402
@@ -35,8 +35,12 @@ BF16_FIRST_STEPS_BAR = {"cfg2": 2e-4, "cfg3": 3e-4, "cfg4": 5.2e-4}
 BF16_UNATTENUATED_BAR = {"cfg2_last": 4.8e-2, "cfg2_denoise": 4.7e-2, "cfg3_last": 0.1, "cfg4_last": 4.8e-2, "cfg5_last": 5.0e-2}
 
 
+# single-plane fp16 (FDM_F16, round 6), same places, 2x measured (3.11e-3 / 3.07e-3; tools/measure_f16_bars.py, profiles/r6_f16/bars.txt)
+F16_UNATTENUATED_BAR = {"cfg2_last": 6.2e-3, "cfg2_denoise": 6.2e-3}
+
+
 def _ubar(dtype, key):
-    return BF16_UNATTENUATED_BAR[key] if dtype == BF16 else TOL
+    return BF16_UNATTENUATED_BAR[key] if dtype == BF16 else (F16_UNATTENUATED_BAR[key] if dtype == F16 else TOL)
 
 
 def mad(a, b):
@@ -71,7 +75,7 @@ def test_cfg2_first_steps_vs_oracle(dtype):
     assert worst < _bar(dtype, "cfg2")
 
 
-@pytest.mark.parametrize("dtype", [F32, BF16, F16X3])
+@pytest.mark.parametrize("dtype", [F32, BF16, F16X3, F16])
 def test_cfg2_last_steps_and_direct_denoise_vs_oracle(dtype):
     """cfg2's program at its benched shape (4 clips x 200 frames), un-attenuated: the LAST three DDPM steps (t = 2, 1, 0, injected
     noise, seeded x) and one direct denoiser call at t = 500, clips 0 and 3, against the CPU oracle
@@ -186,7 +190,7 @@ def test_cfg4_biwi_full_ddim_chain(dtype):
 CFG5_MODES = {"f32": (F32, F32, F32, TOL), "bf16": (BF16, BF16, BF16, 3e-4), "f16x3": (F16X3, F16X3, F32, TOL), "f16x3_all": (F16X3, F16X3, F16X3, TOL)}
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16", "f16x3", "f16x3_all"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16x3"])      # ("f16x3_all" -- the VQ decoder on split operands too -- is pinned by test_vq_in_the_contract_mode_vs_golden)
 def test_cfg5_vocaset_end_to_end_composed(mode):
     from fdm_amd.hubert import HubertPlan
     from fdm_amd.vq import VQPlan

@@ -10,13 +10,17 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from fdm_amd.denoiser import DenoiserPlan  # noqa: E402
-from fdm_amd._lib import BF16, F16X3, F32  # noqa: E402
+from fdm_amd._lib import BF16, F16, F16X3, F32  # noqa: E402
 from oracle import fdm_oracle as FO  # noqa: E402
 from oracle import weights as W  # noqa: E402
 
 DEV = "cuda:0"
 TOL32 = 1e-4
 TOLBF = 8e-2
+# single-plane fp16 step program (FDM_F16, round 6: the split kind's hi plane alone -- bf16's bytes and MFMA rate, 11 significand bits):
+# 2x the distance measured on MI355X against the reference goldens (2.86e-3 VOCASET, 2.88e-3 MEAD; tools/measure_f16_bars.py,
+# profiles/r6_f16/bars.txt) -- outside the 1e-4 contract like bf16, 8x closer to the reference at the same speed
+TOLF16 = 6e-3
 # the modes that meet the contract tolerance (BASELINE.json: 1e-4 max-abs vs the reference): exact fp32 MFMA, and split-fp16
 # operands on the 16-bit matrix cores (three MFMA passes per product, 22 significant bits per operand)
 PARITY_MODES = [F32, F16X3]
@@ -57,6 +61,21 @@ def test_single_step_bf16_stated_tolerance(golden, preset):
         plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
         out = plan.denoise(inp["x"].to(DEV), t)
         assert mad(out[0], g[f"x0_L{L}_t{t}"]) < TOLBF, (preset, L, t)
+
+
+@pytest.mark.parametrize("preset", ["vocaset", "mead"])
+def test_single_step_f16_stated_tolerance(golden, preset):
+    """The single-plane fp16 mode against the reference's denoiser outputs: inside 6e-3 where bf16 states 8e-2 (and must stay an
+    order of magnitude inside bf16's measured 2.3e-2 -- otherwise the mode has no reason to exist)."""
+    g = golden(f"fdm_step_{preset}")
+    plan, _ = plan_for(preset, F16)
+    worst = 0.0
+    for (L, t) in g["cases"].tolist():
+        inp = W.synth_inputs(preset, 1, L, seed=100 + L)
+        plan.prepare(inp["hub"], inp["style"], inp.get("emo"), L=L)
+        worst = max(worst, mad(plan.denoise(inp["x"].to(DEV), t)[0], g[f"x0_L{L}_t{t}"]))
+    print(f"[f16 {preset}] max-abs vs reference goldens {worst:.3e} (bar {TOLF16:.0e})")
+    assert worst < TOLF16, preset
 
 
 def test_f16x3_split_sits_at_the_fp32_kernels_distance(golden):

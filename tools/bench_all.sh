@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/bench_all; mkdir -p $O
 for c in cfg2 cfg1 cfg3 cfg4 cfg5; do
-  for dt in bf16 f16x3 f32; do
+  for dt in bf16 f16 f16x3 f32; do
     steps=3; if [ $dt = f32 ]; then steps=2; fi
     extra="--no-cpu-baseline"; if [ $c = cfg2 ] && [ $dt = bf16 ]; then extra=""; fi
     timeout 900 python bench.py --config $c --dtype $dt --steps $steps --warmup 1 --headline-only $extra > $O/${c}_$dt.json 2> $O/${c}_$dt.err
