@@ -95,6 +95,9 @@ template <typename V8> __device__ __forceinline__ void st8(void* p, const V8& v)
   asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(w) : "memory");
 #endif
 }
+// fp16 overflows at 65504: operand copies are clamped (one v_med3_f32; activations / weights on this path are O(1..100), the clamp keeps a stray
+// value -- or a NaN, which med3 maps to the lower bound -- finite)
+__device__ __forceinline__ float clamp_f16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
 // Store 4 consecutive fp32 values v as operand kind T at dst (split kinds: hi plane at dst, lo plane at dst + lo_off).
 template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, long long lo_off, const f32x4& v) {
   using E = typename Opnd<T>::E;
@@ -104,7 +107,7 @@ template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, lon
     typedef __attribute__((ext_vector_type(4))) E e4;
     e4 o;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (E)(std::is_same<E, f16>::value ? fminf(fmaxf(v[j], -65504.f), 65504.f) : v[j]);      // (fp16 overflows at 65504)
+    for (int j = 0; j < 4; ++j) o[j] = (E)(std::is_same<E, f16>::value ? clamp_f16(v[j]) : v[j]);      // (fp16 overflows at 65504)
     st8(dst, o);
   } else {
     typedef __attribute__((ext_vector_type(4))) E e4;
@@ -112,7 +115,7 @@ template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, lon
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       // fp16 overflows at 65504: clamp (activations / weights on this path are O(1..100); a clamp keeps a stray value finite)
-      const float x = std::is_same<E, f16>::value ? fminf(fmaxf(v[j], -65504.f), 65504.f) : v[j];
+      const float x = std::is_same<E, f16>::value ? clamp_f16(v[j]) : v[j];
       h[j] = (E)x;
       l[j] = (E)((x - (float)h[j]) * Opnd<T>::SCALE);
     }
@@ -123,9 +126,9 @@ template <typename T> __device__ __forceinline__ void store_opnd4(void* dst, lon
 template <typename T> __device__ __forceinline__ void store_opnd1(void* dst, long long lo_off, float v) {
   using E = typename Opnd<T>::E;
   if constexpr (Opnd<T>::NP == 1) {
-    *(E*)dst = (E)(std::is_same<E, f16>::value ? fminf(fmaxf(v, -65504.f), 65504.f) : v);
+    *(E*)dst = (E)(std::is_same<E, f16>::value ? clamp_f16(v) : v);
   } else {
-    const float x = std::is_same<E, f16>::value ? fminf(fmaxf(v, -65504.f), 65504.f) : v;
+    const float x = std::is_same<E, f16>::value ? clamp_f16(v) : v;
     const E h = (E)x;
     *(E*)dst = h;
     *((E*)dst + lo_off) = (E)((x - (float)h) * Opnd<T>::SCALE);
