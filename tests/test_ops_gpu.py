@@ -10,7 +10,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from fdm_amd import ops  # noqa: E402
-from fdm_amd._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F16X3, F32)  # noqa: E402
+from fdm_amd._lib import (ACT_GELU_ERF, ACT_GELU_TANH, ACT_LEAKY02, ACT_MISH, ACT_NONE, ACT_RELU, BF16, F16, F16X3, F32)  # noqa: E402
 
 DEV = "cuda:0"
 
@@ -383,7 +383,7 @@ def pack_ref(k, v, Lpad, dtype):
     """Host restatement of the fragment-packed K / V layouts (include/fdm_hip.h, fdm_attn_args).
     k, v: [B, H, L, hd] -> two [B*H, Lpad*hd] tensors (pad keys zero)."""
     B, H, L, hd = k.shape
-    epc = 8 if dtype == BF16 else 4
+    epc = 8 if dtype in (BF16, F16) else 4
     kt_keys = 4 * epc
     nsub, nks = kt_keys // 16, hd // (4 * epc)
     l = torch.arange(L).view(L, 1)
@@ -823,3 +823,62 @@ def test_time_groupnorm_single_launch_and_chunked_forms():
             ops.time_groupnorm(x.to(DEV), gam.to(DEV), bet.to(DEV), B, T, C, y_t=sp, act=ACT_GELU_ERF, dtype=F16X3, scratch=sc)
             assert float((sp.float().reshape(B, T, C) - outs[1]).abs().max()) <= 1e-6 * max(1.0, float(outs[1].abs().max())), (B, T, C, sc is not None)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("M,N,K,act", [(100, 1024, 1024, ACT_NONE), (800, 3072, 1024, ACT_RELU), (257, 192, 2048, ACT_GELU_ERF), (1992, 2048, 1024, ACT_MISH)])
+def test_f16_single_plane_gemm_layernorm_cast(M, N, K, act):
+    """FDM_F16 (round 6: single-plane fp16 operands, the split kind's hi plane alone) at the operator level: GEMM with every epilogue
+    family, the operand copy a LayerNorm writes, and the cast -- against torch fp32 computed from the fp16-rounded inputs (only
+    accumulation and the output rounding differ: 2^-11 relative)."""
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A32 = torch.randn(M, K, generator=g)
+    W32 = torch.randn(N, K, generator=g) / math.sqrt(K)
+    A, W = ops.to_operand(A32.to(DEV), F16), ops.to_operand(W32.to(DEV), F16)
+    assert A.dtype == torch.float16 and torch.equal(A.cpu(), A32.half())          # the cast is round-to-nearest fp16
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref = act_ref(A32.half().float() @ W32.half().float().t() + bias, act) + resid
+    o32 = torch.zeros(M, N, device=DEV)
+    ot = torch.zeros(M, N, device=DEV, dtype=torch.float16)
+    ops.gemm(A, W, M, N, K, bias=bias.to(DEV), act=act, resid=resid.to(DEV), out_f32=o32, out_t=ot)
+    assert rel(o32, ref) < 2e-5 + (2e-4 if act in (ACT_GELU_ERF, ACT_MISH) else 0)      # (the 16-bit kinds take the hardware exp forms)
+    assert rel(ot.float(), ref) < 1e-3
+    # every tile gives the same bits in this kind too
+    o2 = torch.zeros(M, N, device=DEV)
+    for tile in (1, 2, 3, 12):
+        ops.gemm(A, W, M, N, K, bias=bias.to(DEV), act=act, resid=resid.to(DEV), out_f32=o2, tile=tile)
+        assert torch.equal(o2, o32), tile
+    d = 1024 if N >= 1024 else 256
+    x = torch.randn(M, d, generator=g) * 2 + 0.3
+    gamma, beta = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    yt = torch.zeros(M, d, device=DEV, dtype=torch.float16)
+    y32 = torch.zeros(M, d, device=DEV)
+    ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV), M, d, y_f32=y32, y_t=yt, dtype=F16)
+    assert rel(y32, F.layer_norm(x, (d,), gamma, beta, 1e-5)) < 1e-5 and torch.equal(yt.cpu(), y32.cpu().half())
+    big = torch.tensor([1e6, -1e6, 65504.0, 3.0], device=DEV).repeat(4)
+    assert torch.equal(ops.to_operand(big, F16).cpu(), torch.tensor([65504.0, -65504.0, 65504.0, 3.0]).repeat(4).half())     # clamped, never inf
+
+
+@pytest.mark.parametrize("B,H,L,hd,causal,period", [(4, 8, 200, 128, True, 30), (2, 16, 98, 64, False, 1), (2, 4, 75, 256, True, 25)])
+def test_f16_single_plane_attention_via_qkv_gemm(B, H, L, hd, causal, period):
+    """The FDM_F16 attention kernel behind the QKV GEMM's packed K / V epilogue, against torch on the fp16-rounded Q, K, V."""
+    g = torch.Generator().manual_seed(L + hd)
+    d = H * hd
+    x = torch.randn(B * L, d, generator=g).half()
+    Wqkv = (torch.randn(3 * d, d, generator=g) / math.sqrt(d)).half()
+    bqkv = 0.1 * torch.randn(3 * d, generator=g)
+    q_t = torch.zeros(B * L, d, device=DEV, dtype=torch.float16)
+    kp, vp, Lpad = ops.kv_buffers(B, H, L, hd, torch.float16, DEV)
+    ops.gemm(x.to(DEV), Wqkv.to(DEV), B * L, 3 * d, d, bias=bqkv.to(DEV), out_t=q_t, ldo_t=d,
+             out_kp=kp, kp_col0=d, out_vp=vp, vp_col0=2 * d, kv_L=L, kv_Lpad=Lpad, kv_hd=hd)
+    slopes = torch.tensor([2.0 ** (-(i + 1)) for i in range(H)])
+    scale = 1.0 / math.sqrt(hd)
+    o = torch.zeros(B * L, d, device=DEV, dtype=torch.float16)
+    ops.attention(q_t, kp, vp, o, B=B, H=H, L=L, hd=hd, ldq=d, ldo=d, Lpad=Lpad,
+                  scale=scale, causal=causal, slopes=slopes.to(DEV) if causal else None, period=period)
+    qkv = (x.float() @ Wqkv.float().t() + bqkv).half().float()
+    q, k, v = [t.view(B, L, H, hd).transpose(1, 2) for t in qkv.split(d, 1)]
+    kref, vref = pack_ref(k, v, Lpad, F16)
+    assert rel(q_t.float(), qkv[:, :d]) < 1e-3 and rel(kp.float(), kref) < 1e-3 and rel(vp.float(), vref) < 1e-3
+    ref = mha_ref(q, k, v, scale, alibi(H, L, period, slopes) if causal else None).transpose(1, 2).reshape(B * L, d)
+    assert rel(o.float(), ref) < 3e-3
