@@ -183,7 +183,14 @@ static void run_chain(Ctx& c, const char* name, const std::string& pattern, int 
 
 int main(int argc, char** argv) {
   Ctx c{};
-  CK(hipStreamCreate(&c.s));
+  if (const char* pr = getenv("FDM_PROBE_PRIO")) {      // FDM_PROBE_PRIO=high|low: does the queue's priority move the dependent-launch boundary?
+    int lo = 0, hi = 0;
+    CK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // (numerically lower = higher priority)
+    CK(hipStreamCreateWithPriority(&c.s, hipStreamNonBlocking, pr[0] == 'h' ? hi : lo));
+    printf("stream priority %s (range %d..%d)\n", pr, lo, hi);
+  } else {
+    CK(hipStreamCreate(&c.s));
+  }
   const int N = 1024, K = 1024, MMAX = 1600;
   std::vector<unsigned short> hw((size_t)N * K);
   srand(1);
