@@ -689,12 +689,20 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_glds_kernel(const vo
   if (stamps && tid == 0) stamps[2] = wall_clock64();
 #endif
   if constexpr (LW > 0) wait_vmcnt<0>();      // the epilogue operands requested before the loop (a compute wave has no other load in flight)
+#ifndef FDM_GEMM_STAMPS
   gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(pe, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
-#ifdef FDM_GEMM_STAMPS
-  if (stamps && tid == 0) stamps[3] = wall_clock64();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (stamps && tid == 0) stamps[4] = wall_clock64();
+#else
+  // (instrumented build: with FDM_EPI_PASSES = 2 in the environment of the probe -- carried in fdm_gemm_args.sched.advance -- the epilogue runs twice over
+  //  the SAME instructions, the second pass with a warm instruction cache: stamps [6] / [7] = its stores issued / acknowledged)
+  const int passes = (stamps && p.sched.advance == 2 && !SCHED) ? 2 : 1;
+#pragma clang loop unroll(disable)
+  for (int pass = 0; pass < passes; ++pass) {
+    gemm_epilogue<T, BM, BN, WM, WN, HEAVY, SCHED, SPEC>(pe, acc, epre, m0, n0, z, wm, wn, g, r16, rowstat, smem);
+    if (stamps && tid == 0) stamps[pass == 0 ? 3 : 6] = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (stamps && tid == 0) stamps[pass == 0 ? 4 : 7] = wall_clock64();
+  }
 #endif
 }
 
