@@ -13,6 +13,9 @@
 #include "../face-diffusion-model_amd/csrc/gemm.hpp"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+#ifndef LWP_KCH
+#define LWP_KCH 8      // 16-byte chunks of K per LDS row: 8 (64-deep k-tiles) or 16 (128-deep: half the barriers per K)
+#endif
 #ifndef LWP_BM
 #define LWP_BM 128
 #define LWP_BN 64
@@ -41,7 +44,7 @@ int main(int argc, char** argv) {
     a.out_t = out; a.ldo_t = N; a.ldr = N; a.ldo_f32 = N; a.ln_eps = 1e-5f;
     auto run = [&](int i) {
       a.W = W[i % 8];
-      hipError_t e = fdm::gemm_glds_launch_h<fdm::bf16, LWP_BM, LWP_BN, LWP_WM, LWP_WN, LWP_NST, 8, false, false, fdm::GEMM_LEAN, LWP_LW>(a, s);
+      hipError_t e = fdm::gemm_glds_launch_h<fdm::bf16, LWP_BM, LWP_BN, LWP_WM, LWP_WN, LWP_NST, LWP_KCH, false, false, fdm::GEMM_LEAN, LWP_LW>(a, s);
       if (e != hipSuccess) { printf("launch: %s\n", hipGetErrorString(e)); exit(1); }
     };
     for (int i = 0; i < 8; ++i) run(i);
@@ -63,8 +66,8 @@ int main(int argc, char** argv) {
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / reps / 16, nk = K / 64.0;
     const long long wgs = (long long)((M + LWP_BM - 1) / LWP_BM) * ((N + LWP_BN - 1) / LWP_BN);
-    printf("variant %d tile %dx%d (%dx%d waves, %d stages, %d loaders) M=%d N=%d K=%d %lld WGs: %.2f us per launch, %.3f us per k-tile, %.0f TFLOP/s if it were the full kernel\n",
-           FDM_LW_VARIANT, LWP_BM, LWP_BN, LWP_WM, LWP_WN, LWP_NST, LWP_LW, M, N, K, wgs, us, us / nk, 2.0 * M * N * K / us / 1e6);
+    printf("variant %d tile %dx%d%s (%dx%d waves, %d stages, %d loaders) M=%d N=%d K=%d %lld WGs: %.2f us per launch, %.3f us per k-tile, %.0f TFLOP/s if it were the full kernel\n",
+           FDM_LW_VARIANT, LWP_BM, LWP_BN, LWP_KCH == 16 ? "k128" : "", LWP_WM, LWP_WN, LWP_NST, LWP_LW, M, N, K, wgs, us, us / nk, 2.0 * M * N * K / us / 1e6);
     CK(hipGraphExecDestroy(x)); CK(hipGraphDestroy(g));
     CK(hipFree(A)); CK(hipFree(out)); CK(hipFree(bias));
     for (int i = 0; i < 8; ++i) CK(hipFree(W[i]));
