@@ -429,8 +429,8 @@ def test_vq_index_mismatch_rate_against_the_reference_formula():
     chain outputs (cfg2-shaped VOCASET and cfg3-shaped MEAD + CFG DDIM chains from fresh seeds, scaled as bench.py scales them before
     quant), VOCASET / all 7 EVQ slices of MEAD / BIWI (c = 128).  The two sides evaluate the same real-number expression in different
     fp32 orders (an fmaf chain per sum here, the BLAS's blocking there), so they can only disagree where the two best codes are
-    closer than the rounding of that expression: every mismatching row must be such a near-tie under fp64 (bound: 8 ulp of the
-    expansion's largest term), and the count is printed -- it is the figure DESIGN.md quotes beside "bit-identical on the index path"."""
+    closer than the rounding of that expression: every mismatching row must be such a near-tie under fp64 (bound: the worst-case
+    rounding of its c-term fp32 sums, c * 2^-24 of the expansion's largest term; observed: printed), and the count is printed -- it is the figure DESIGN.md quotes beside "bit-identical on the index path"."""
     import os
     from fdm_amd.denoiser import DenoiserPlan
     total = int(float(os.environ.get("FDM_VQ_RATE_ROWS", "1e7")))
@@ -453,7 +453,9 @@ def test_vq_index_mismatch_rate_against_the_reference_formula():
             dk, dr = d64.gather(1, idx[bad].view(-1, 1)).view(-1), d64.gather(1, ridx[bad].view(-1, 1)).view(-1)
             big = (zb ** 2).sum(1) + (E64 ** 2).sum(1).max() + 2 * (zb @ E64.t()).abs().max(1).values
             gap = (dk - dr).abs()
-            assert bool((gap <= 8 * 2.0 ** -24 * big).all()), (name, float((gap / big).max()))      # a near-tie: below the fp32 rounding of the expression
+            # a near-tie: the two codes' exact distances differ by less than the worst-case fp32 rounding of the expression's c-term sums (c * 2^-24 of its largest term)
+            assert bool((gap <= z.shape[1] * 2.0 ** -24 * big).all()), (name, float((gap / big).max()))
+            s.append(float((gap / big).max()))
             best = d64.min(1).values
             s[1] += int(bad.numel()); s[2] += int((gap == 0).sum()); s[3] += int((dk == best).sum()); s[4] += int((dr == best).sum())
 
@@ -502,5 +504,7 @@ def test_vq_index_mismatch_rate_against_the_reference_formula():
     for name, s in stats.items():
         print(f"[vq index rate] {name}: {s[0]} rows, {s[1]} differ from the reference's expression ({s[1] / max(s[0], 1):.2e}); of those: exact fp64 ties {s[2]}, "
               f"kernel took the fp64-nearest code {s[3]}, the reference's expression took it {s[4]}")
-    print(f"[vq index rate] total: {rows} rows, {mism} mismatches = {mism / rows:.2e} per row, every one a near-tie below the fp32 rounding of the expression")
+    worst = max([g_ for s in stats.values() for g_ in s[5:]] or [0.0])
+    print(f"[vq index rate] total: {rows} rows, {mism} mismatches = {mism / rows:.2e} per row, every one a near-tie below the fp32 rounding of the expression "
+          f"(largest gap between the two codes' exact distances: {worst:.1e} of the expression's largest term)")
     assert rows >= 0.95 * total
